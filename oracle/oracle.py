@@ -1,0 +1,255 @@
+"""ctypes front-end for oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (see oracle/kdtree_oracle.c header).  Nothing under
+volumerenderer_amd/ imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH)
+        for s in ("kdtree_oracle.c", "raymarch_oracle.c", "Makefile")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class TraceRec(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("epoch", C.c_int32), ("kind", C.c_int32),
+                ("distance", C.c_double), ("error", C.c_double), ("df", C.c_double), ("step", C.c_double)]
+
+
+class Camera(C.Structure):
+    """Mirrors vr_camera in include/vrhip.h (main.cpp:33-40,396-397)."""
+    _fields_ = [("pos", C.c_float * 3), ("front", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov_deg", C.c_float), ("z_near", C.c_float), ("z_far", C.c_float)]
+
+
+class RenderParams(C.Structure):
+    """Mirrors vr_render_params in include/vrhip.h (main.cpp:330-334, raycaster.frag:14)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("step_size", C.c_float * 3),
+                ("iso_value", C.c_float), ("max_samples", C.c_int32), ("mode", C.c_int32),
+                ("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("sample_offset", C.c_int32),
+                ("no_early_exit", C.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    p, u8p, i64, i32 = C.c_void_p, C.POINTER(C.c_uint8), C.c_int64, C.c_int32
+    L.vko_create.restype = p
+    L.vko_create.argtypes = [p, i64, i64, i64]
+    L.vko_destroy.argtypes = [p]
+    for name in ("vko_set_error_tolerance", "vko_set_max_epochs", "vko_set_guarded", "vko_set_midrange"):
+        getattr(L, name).argtypes = [p, C.c_int]
+    L.vko_build_to_stage.argtypes = [p, C.c_int]
+    L.vko_build_to_stage.restype = C.c_int
+    L.vko_build.argtypes = [p]
+    L.vko_level_cut.argtypes = [p, C.c_int, p]
+    L.vko_level_cut.restype = C.c_int
+    L.vko_save.argtypes = [p, C.c_char_p]
+    L.vko_open.argtypes = [C.c_char_p]
+    L.vko_open.restype = p
+    for name in ("vko_orig_tree_depth", "vko_max_tree_depth", "vko_num_reverts", "vko_zero_run_rewrites",
+                 "vko_trace_len"):
+        getattr(L, name).argtypes = [p]
+        getattr(L, name).restype = i32
+    for name in ("vko_num_active_nodes", "vko_num_orig_nodes", "vko_first_orig_leaf", "vko_tree_bytes",
+                 "vko_temp_len", "vko_recon_len", "vko_tree_range_bytes"):
+        getattr(L, name).argtypes = [p]
+        getattr(L, name).restype = i64
+    for name in ("vko_tree_ptr", "vko_distance_map_ptr", "vko_temp_ptr", "vko_recon_ptr", "vko_tree_range_ptr",
+                 "vko_distance_map_range_ptr", "vko_temp_range_ptr", "vko_recon_range_ptr"):
+        getattr(L, name).argtypes = [p]
+        getattr(L, name).restype = u8p
+    L.vko_trace_ptr.argtypes = [p]
+    L.vko_trace_ptr.restype = C.POINTER(TraceRec)
+    L.vko_dims.argtypes = [p, C.POINTER(i64)]
+    L.vko_fnv1a64.argtypes = [p, i64]
+    L.vko_fnv1a64.restype = C.c_uint64
+    L.vko_gen_sphere.argtypes = [p, C.c_int, C.c_int, C.c_uint32]
+    L.vko_measure_max_error.argtypes = [p, p, i64]
+    L.vko_measure_max_error.restype = C.c_int
+    L.vko_measure_mean_error.argtypes = [p, p, i64]
+    L.vko_measure_mean_error.restype = C.c_double
+    L.vko_query_error.argtypes = [p, p, i64, p]
+    L.vko_mid_convert_to_byte_array.argtypes = [p, p, i64]
+    L.vko_mid_convert_to_byte_array.restype = i64
+    L.vko_leaf_stats.argtypes = [p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if hasattr(L, "vro_render"):
+        L.vro_render.argtypes = [p, i64, i64, i64, C.POINTER(Camera), C.POINTER(RenderParams), p]
+        L.vro_render.restype = C.c_int
+        L.vro_composite_over.argtypes = [p, p, i64]
+    _lib = L
+    return L
+
+
+def _u8(ptr, n):
+    if n <= 0:
+        return np.zeros(0, np.uint8)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).copy()
+
+
+def fnv1a64(arr) -> int:
+    a = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+    return int(lib().vko_fnv1a64(a.ctypes.data, a.size))
+
+
+def gen_sphere(n, noise_mask=7, seed=12345):
+    """SURVEY.md section 8d generator (sphere_n3: mask 7, sphere_n0: mask 0, random: mask>=256)."""
+    v = np.empty(n * n * n, np.uint8)
+    lib().vko_gen_sphere(v.ctypes.data, n, noise_mask, seed)
+    return v.reshape(n, n, n)  # [z][y][x]
+
+
+class OracleTree:
+    """Mirror of the reference's class VolumeKdtree (VolumeKdtree_recover.h:51-264).
+
+    `voxels` is a uint8 array in x-fastest order (shape [Z][Y][X] or flat)."""
+
+    def __init__(self, voxels=None, dims=None, tolerance=6, max_epochs=5, guarded=False, midrange=False,
+                 _handle=None):
+        self._L = lib()
+        if _handle is not None:
+            self._h = _handle
+            self._vox = None
+            return
+        v = np.ascontiguousarray(voxels, dtype=np.uint8)
+        if dims is None:
+            z, y, x = v.shape
+            dims = (x, y, z)
+        assert v.size == dims[0] * dims[1] * dims[2]
+        self._vox = v.reshape(-1)
+        self._h = self._L.vko_create(self._vox.ctypes.data, dims[0], dims[1], dims[2])
+        self._L.vko_set_error_tolerance(self._h, tolerance)
+        self._L.vko_set_max_epochs(self._h, max_epochs)
+        self._L.vko_set_guarded(self._h, int(guarded))
+        self._L.vko_set_midrange(self._h, int(midrange))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.vko_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def open(cls, path):
+        h = lib().vko_open(os.fsencode(path))
+        if not h:
+            raise FileNotFoundError(path)
+        return cls(_handle=h)
+
+    def save(self, path):
+        rc = self._L.vko_save(self._h, os.fsencode(path))
+        if rc != 0:
+            raise RuntimeError("vko_save failed: %d" % rc)
+
+    def build(self, stage=4):
+        rc = self._L.vko_build_to_stage(self._h, stage)
+        if rc != 0:
+            raise RuntimeError("vko_build failed: %d" % rc)
+        return self
+
+    # -- public members of the reference class
+    @property
+    def origTreeDepth(self): return self._L.vko_orig_tree_depth(self._h)
+    @property
+    def maxTreeDepth(self): return self._L.vko_max_tree_depth(self._h)
+    @property
+    def numActiveNodes(self): return self._L.vko_num_active_nodes(self._h)
+    @property
+    def numOrigNodes(self): return self._L.vko_num_orig_nodes(self._h)
+    @property
+    def firstOrigLeaf(self): return self._L.vko_first_orig_leaf(self._h)
+    @property
+    def dims(self):
+        d = (C.c_int64 * 3)()
+        self._L.vko_dims(self._h, d)
+        return tuple(d)
+    @property
+    def tree(self): return _u8(self._L.vko_tree_ptr(self._h), self._L.vko_tree_bytes(self._h))
+    @property
+    def distanceMap(self): return _u8(self._L.vko_distance_map_ptr(self._h), self.maxTreeDepth + 1)
+    @property
+    def temp(self): return _u8(self._L.vko_temp_ptr(self._h), self._L.vko_temp_len(self._h))
+    @property
+    def recon(self): return _u8(self._L.vko_recon_ptr(self._h), self._L.vko_recon_len(self._h))
+    @property
+    def tree_range(self): return _u8(self._L.vko_tree_range_ptr(self._h), self._L.vko_tree_range_bytes(self._h))
+    @property
+    def distanceMap_range(self): return _u8(self._L.vko_distance_map_range_ptr(self._h), self.maxTreeDepth + 1)
+    @property
+    def temp_range(self): return _u8(self._L.vko_temp_range_ptr(self._h), self._L.vko_temp_len(self._h))
+    @property
+    def recon_range(self): return _u8(self._L.vko_recon_range_ptr(self._h), self._L.vko_recon_len(self._h))
+    @property
+    def numReverts(self): return self._L.vko_num_reverts(self._h)
+    @property
+    def zeroRunRewrites(self): return self._L.vko_zero_run_rewrites(self._h)
+
+    def trace(self):
+        n = self._L.vko_trace_len(self._h)
+        ptr = self._L.vko_trace_ptr(self._h)
+        return [dict(depth=ptr[i].depth, epoch=ptr[i].epoch, kind=ptr[i].kind, distance=ptr[i].distance,
+                     error=ptr[i].error, df=ptr[i].df, step=ptr[i].step) for i in range(n)]
+
+    def leaf_stats(self):
+        a, b = C.c_int32(), C.c_int32()
+        c, d = C.c_double(), C.c_double()
+        self._L.vko_leaf_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(max_before=a.value, max_after=b.value, l1_before=c.value, l1_after=d.value)
+
+    def levelCut(self, cutDepth=None, out=None):
+        X, Y, Z = self.dims
+        if cutDepth is None:
+            cutDepth = self.maxTreeDepth
+        if out is None:
+            out = np.zeros(X * Y * Z, np.uint8)
+        rc = self._L.vko_level_cut(self._h, cutDepth, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("vko_level_cut: malformed stream (%d)" % rc)
+        return out.reshape(Z, Y, X)
+
+    def convertToByteArray(self):
+        n = self._L.vko_mid_convert_to_byte_array(self._h, None, 0)
+        if n < 0:
+            raise RuntimeError("not a MidRangeTree")
+        out = np.zeros(n, np.uint8)
+        self._L.vko_mid_convert_to_byte_array(self._h, out.ctypes.data, n)
+        return out
+
+
+def measure_max_error(decoded, original):
+    a = np.ascontiguousarray(decoded, np.uint8).reshape(-1)
+    b = np.ascontiguousarray(original, np.uint8).reshape(-1)
+    return int(lib().vko_measure_max_error(a.ctypes.data, b.ctypes.data, a.size))
+
+
+def measure_mean_error(decoded, original):
+    a = np.ascontiguousarray(decoded, np.uint8).reshape(-1)
+    b = np.ascontiguousarray(original, np.uint8).reshape(-1)
+    return float(lib().vko_measure_mean_error(a.ctypes.data, b.ctypes.data, a.size))
+
+
+def query_error(decoded, original):
+    a = np.ascontiguousarray(decoded, np.uint8).reshape(-1)
+    b = np.ascontiguousarray(original, np.uint8).reshape(-1)
+    out = np.empty_like(a)
+    lib().vko_query_error(a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data)
+    return out.reshape(np.shape(decoded))

@@ -1,0 +1,98 @@
+"""Pins the CPU oracle (oracle/kdtree_oracle.c) to outputs of the reference itself.
+
+The only reference outputs that exist for this path are the known-answer values
+the survey recorded and the tree file the
+reference's own save() wrote for the 16^3 case; see tests/golden/
+survey_known_answers.json for provenance.  Bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KA = json.load(open(os.path.join(GOLD, "survey_known_answers.json")))
+
+
+@pytest.mark.parametrize("case", KA["volume_kdtree"], ids=lambda c: "n%d" % c["n"])
+def test_volume_kdtree_known_answers(oracle, case, tmp_path):
+    O = oracle
+    vol = O.gen_sphere(case["n"], case["noise_mask"])
+    t = O.OracleTree(vol.copy(), tolerance=case["tolerance"], max_epochs=case["max_epochs"]).build()
+    if "origTreeDepth" in case:
+        assert t.origTreeDepth == case["origTreeDepth"]
+        assert t.maxTreeDepth == case["maxTreeDepth"]
+    if "numActiveNodes" in case:
+        assert t.numActiveNodes == case["numActiveNodes"]
+        assert len(t.tree) == case["tree_bytes"]
+    if "distanceMap" in case:
+        assert list(map(int, t.distanceMap)) == case["distanceMap"]
+    assert "%016x" % O.fnv1a64(t.tree) == case["tree_fnv"]
+    out = t.levelCut()
+    if "voxels_fnv" in case:
+        assert "%016x" % O.fnv1a64(out) == case["voxels_fnv"]
+    if "decoded_max_error" in case:
+        assert O.measure_max_error(out, vol) == case["decoded_max_error"]
+    if "saved_file" in case:
+        # byte-identical to the file the reference's save() wrote (R.cpp:521-552)
+        p = str(tmp_path / "t.bin")
+        t.save(p)
+        ref = open(os.path.join(GOLD, case["saved_file"]), "rb").read()
+        assert len(ref) == case["saved_file_bytes"]
+        assert open(p, "rb").read() == ref
+        # open() of the reference-written file: 8-byte over-allocation (C-6), same voxels
+        u = O.OracleTree.open(os.path.join(GOLD, case["saved_file"]))
+        assert len(u.tree) == case["tree_bytes"] + 8
+        assert u.numActiveNodes == case["numActiveNodes"]
+        assert np.array_equal(u.levelCut(), out)
+
+
+@pytest.mark.parametrize("case", KA["mid_range_tree"], ids=lambda c: "n%d" % c["n"])
+def test_mid_range_tree_known_answers(oracle, case):
+    O = oracle
+    vol = O.gen_sphere(case["n"], case["noise_mask"])
+    t = O.OracleTree(vol.copy(), tolerance=case["tolerance"], max_epochs=case["max_epochs"],
+                     midrange=True, guarded=True).build()
+    assert t.numActiveNodes == case["numActiveNodes"]
+    assert "%016x" % O.fnv1a64(t.tree) == case["tree_fnv"]
+    assert "%016x" % O.fnv1a64(t.tree_range) == case["tree_range_fnv"]
+    packed = t.convertToByteArray()
+    assert len(packed) == case["packed_bytes"]
+    assert "%016x" % O.fnv1a64(packed) == case["packed_fnv"]
+    assert O.measure_max_error(t.levelCut(), vol) == case["decoded_max_error"]
+
+
+def test_guarded_variant_is_output_identical(oracle):
+    """VolumeKdtree.cpp:333 only skips work whose result is never used."""
+    O = oracle
+    vol = O.gen_sphere(32, 7)
+    for ep in (1, 2, 5):
+        a = O.OracleTree(vol.copy(), tolerance=2, max_epochs=ep).build()
+        b = O.OracleTree(vol.copy(), tolerance=2, max_epochs=ep, guarded=True).build()
+        assert np.array_equal(a.tree, b.tree) and np.array_equal(a.distanceMap, b.distanceMap)
+
+
+def test_oracle_properties(oracle):
+    O = oracle
+    rng = np.random.default_rng(7)
+    # all-zero volume: a single pruned root token
+    z = np.zeros((8, 8, 8), np.uint8)
+    t = O.OracleTree(z.copy(), tolerance=1, max_epochs=2).build()
+    assert t.numActiveNodes == 1 and list(t.tree) == [3]
+    assert np.array_equal(t.levelCut(), z)
+    # constant volume: root code 1 + two pruned children
+    c = np.full((8, 8, 8), 37, np.uint8)
+    t = O.OracleTree(c.copy(), tolerance=1, max_epochs=2).build()
+    assert t.numActiveNodes == 3 and int(t.distanceMap[0]) == 37
+    assert np.array_equal(t.levelCut(), c)
+    # maxEpochs == 1: no revert possible -> decoded error <= tolerance
+    for tol in (0, 1, 3, 6):
+        v = rng.integers(0, 256, (16, 16, 8), dtype=np.uint8)
+        t = O.OracleTree(v.copy(), tolerance=tol, max_epochs=1).build()
+        assert t.numReverts == 0
+        assert O.measure_max_error(t.levelCut(), v) <= tol
+        assert t.zeroRunRewrites == 0
+    # non power-of-two extents run (C-10): decode is well formed
+    v = rng.integers(0, 256, (5, 6, 12), dtype=np.uint8)
+    t = O.OracleTree(v.copy(), tolerance=1, max_epochs=2).build()
+    t.levelCut()
