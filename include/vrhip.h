@@ -1,0 +1,197 @@
+/*
+ * vrhip.h -- C ABI of the MI355X-native kd-tree volume codec + ray-march compositor.
+ *
+ * This is the drop-in boundary for ONE hot path of AugmentariumLab/VolumeRenderer:
+ *   ingest   VolumeReader<T>::LoadBricksToTexture        volume_renderer/VolumeReader.h:151-223
+ *   encode   VolumeKdtree::build                          volume_renderer/VolumeKdTree_recover.cpp:17-140
+ *   decode   VolumeKdtree::levelCut                       volume_renderer/VolumeKdTree_recover.cpp:726-835
+ *   file     VolumeKdtree::save / open                    volume_renderer/VolumeKdTree_recover.cpp:521-594
+ *   4-bit    MidRangeTree::build / convertToByteArray     volume_renderer/MidRangeTree.cpp:17-176,1095-1128
+ *   render   raycaster.frag / isosurface.frag + UnitBrick::Draw
+ *                                                         volume_renderer/raycaster.frag:18-86,
+ *                                                         volume_renderer/isosurface.frag:77-159,
+ *                                                         volume_renderer/UnitBrick.h:98-100
+ * The reference has no FFI layer; its boundary is the public surface of those C++
+ * classes, called from main.cpp:142-290,358-404.  The headers in include/vrhip/ re-create
+ * that surface (same class and method names) as a header-only facade over the
+ * functions below.  Everything behind this header is hand-written HIP for gfx950;
+ * there is NO CPU fallback: every compute entry point returns VR_ERR_NO_DEVICE
+ * when no HIP device is usable.
+ *
+ * Conventions
+ *  - plain C, no exceptions across the boundary, every function returns vr_status;
+ *  - volumes are uint8, x fastest: cell(x,y,z) = x + X*y + X*Y*z (R.cpp:4-6);
+ *  - "dev" pointers are HIP device pointers, "host" pointers ordinary memory;
+ *    the caller owns every buffer it passes;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls
+ *    that return data to the host synchronise that stream before returning;
+ *    device-to-device calls are asynchronous on it.
+ *  - a vr_brickset is a batch of B independent bricks of identical dimensions, one
+ *    kd-tree per brick (a single VolumeKdtree is a brickset with B = 1).  All B
+ *    trees are built / decoded by the same batched kernel launches.
+ */
+#ifndef VRHIP_H
+#define VRHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t vr_status;
+enum {
+    VR_OK = 0,
+    VR_ERR_INVALID = -1,     /* bad argument (null pointer, non power-of-two dims, negative tolerance ...) */
+    VR_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP call failed; there is no CPU fallback */
+    VR_ERR_OOM = -3,
+    VR_ERR_IO = -4,          /* save/open: file missing or short (reference: exit(-1), R.cpp:560-565) */
+    VR_ERR_STATE = -5,       /* e.g. decode before build, save of an empty tree (R.cpp:526-530) */
+    VR_ERR_FORMAT = -6,      /* malformed tree stream */
+    VR_ERR_UNSUPPORTED = -7
+};
+
+/* Which reference class the brickset mirrors. */
+enum {
+    VR_VARIANT_RECOVER = 0,  /* VolumeKdTree_recover.cpp (live copy)                         */
+    VR_VARIANT_GUARDED = 1,  /* VolumeKdtree.cpp:333 guard -- byte-identical output, less work */
+    VR_VARIANT_MIDRANGE = 2  /* MidRangeTree.cpp: second 2-bit stream + 4-bit packing         */
+};
+
+typedef struct vr_brickset vr_brickset;
+
+/* Mirrors the public data members of class VolumeKdtree (VolumeKdtree_recover.h:57-79). */
+typedef struct vr_tree_info {
+    int64_t X, Y, Z;             /* brick dimensions                               */
+    int32_t orig_tree_depth;     /* origTreeDepth  (R.cpp:29)                      */
+    int32_t max_tree_depth;      /* maxTreeDepth = orig + 7 (R.cpp:30)             */
+    int64_t num_active_nodes;    /* numActiveNodes (R.cpp:714)                     */
+    int64_t tree_bytes;          /* tree.bytes() = ceil(numActiveNodes / 4)        */
+    int32_t tolerance, max_epochs, variant;
+    int32_t num_reverts;         /* gradient-descent reverts taken (defect C-2 indicator) */
+    int32_t max_error_before;    /* encoder's own leaf max error before branch growth (R.cpp:71-76) */
+    int32_t max_error_after;     /* ... after branch growth (R.cpp:115-120)        */
+    double  mean_l1_after;       /* (R.cpp:122-129)                                */
+} vr_tree_info;
+
+/* ---- library / device ------------------------------------------------------- */
+vr_status vr_device_count(int32_t *count);                 /* VR_OK + 0 devices is possible (CPU-only box) */
+vr_status vr_set_device(int32_t device);
+const char *vr_status_string(vr_status s);
+const char *vr_version(void);
+
+/* ---- brickset life cycle ------------------------------------------------------
+ * VolumeKdtree(std::vector<byte>&, x, y, z) + setErrorTolerance + setMaxEpochs
+ * (VolumeKdtree_recover.h:103-112, R.cpp:9-15).  dims must be powers of two
+ * (the reference's brick sizes 256x256x128 / 256^3 are); other extents return
+ * VR_ERR_UNSUPPORTED (reference behaviour for them is lossy). */
+vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_t dims[3],
+                             int32_t tolerance, int32_t max_epochs, int32_t variant);
+vr_status vr_brickset_destroy(vr_brickset *bs);
+vr_status vr_brickset_set_error_tolerance(vr_brickset *bs, int32_t tolerance);   /* R.cpp:9-11  */
+vr_status vr_brickset_set_max_epochs(vr_brickset *bs, int32_t max_epochs);       /* R.cpp:13-15 */
+
+/* ---- encode: VolumeKdtree::build (R.cpp:17-140) --------------------------------
+ * voxels_dev: num_bricks * X*Y*Z bytes, brick b at offset b*X*Y*Z, each x-fastest.
+ * Unlike the reference (R.cpp:51-52) the input buffer is left untouched.
+ * Asynchronous on `stream`; vr_brickset_info()/get_* synchronise. */
+vr_status vr_brickset_build(vr_brickset *bs, const uint8_t *voxels_dev, void *stream);
+
+/* Public members after build(): per-brick info, tree bytes (TwoBitArray::bits of
+ * the preorder stream), distanceMap (maxTreeDepth+1 bytes). */
+vr_status vr_brickset_info(vr_brickset *bs, int32_t brick, vr_tree_info *info);
+vr_status vr_brickset_get_tree(vr_brickset *bs, int32_t brick, uint8_t *dst_host, int64_t capacity);
+vr_status vr_brickset_get_distance_map(vr_brickset *bs, int32_t brick, uint8_t *dst_host, int32_t capacity);
+/* MidRangeTree only: tree_range.bits, distanceMap_range, convertToByteArray (M.cpp:1095-1128);
+ * packed length is returned through *length (pass dst_host = NULL to query it). */
+vr_status vr_brickset_get_tree_range(vr_brickset *bs, int32_t brick, uint8_t *dst_host, int64_t capacity);
+vr_status vr_brickset_get_distance_map_range(vr_brickset *bs, int32_t brick, uint8_t *dst_host, int32_t capacity);
+vr_status vr_brickset_get_packed4(vr_brickset *bs, int32_t brick, uint8_t *dst_host, int64_t capacity, int64_t *length);
+
+/* ---- decode: VolumeKdtree::levelCut (R.cpp:726-835) ----------------------------
+ * out_dev: num_bricks * X*Y*Z bytes.  cut_depth must equal max_tree_depth (the only
+ * depth at which the reference's walk is well defined) or be
+ * < 0 (= max_tree_depth).  Asynchronous on `stream`. */
+vr_status vr_brickset_decode(vr_brickset *bs, int32_t cut_depth, uint8_t *out_dev, void *stream);
+
+/* Install a foreign preorder stream (e.g. read from a reference-written file) as
+ * brick `brick`: builds the decode side-car index from the bytes alone. */
+vr_status vr_brickset_set_tree(vr_brickset *bs, int32_t brick, const uint8_t *tree_host, int64_t tree_bytes,
+                               int64_t num_active_nodes, const uint8_t *distance_map_host, int32_t map_len);
+
+/* ---- file format: VolumeKdtree::save / open (R.cpp:521-594) --------------------
+ * Byte-identical to the reference's file: rootMin,rootMax (3x int64 each),
+ * maxTreeDepth, origTreeDepth (int32), X,Y,Z,numActiveNodes (int64), distanceMap,
+ * tree bytes.  vr_brickset_open creates a 1-brick set. */
+vr_status vr_brickset_save(vr_brickset *bs, int32_t brick, const char *path);
+vr_status vr_brickset_open(vr_brickset **out, const char *path);
+
+/* ---- error helpers: measureMaxError / measureMeanError / queryError (R.cpp:386-411)
+ * The reference dereferences the input it has already cleared (SURVEY C-7); here the
+ * original volume is passed explicitly.  n = number of voxels. */
+vr_status vr_measure_error(const uint8_t *decoded_dev, const uint8_t *original_dev, int64_t n,
+                           int32_t *max_error, double *mean_error, void *stream);
+vr_status vr_query_error(const uint8_t *decoded_dev, const uint8_t *original_dev, int64_t n,
+                         uint8_t *error_dev, void *stream);
+
+/* ---- ingest: VolumeReader<T>::LoadBricksToTexture (VolumeReader.h:151-223) ------
+ * Places brick b (brick_dims, x-fastest, contiguous at bricks_dev + b*brick_voxels)
+ * at grid cell brick_ijk[3*b..3*b+2] of a global x-fastest volume of
+ * (I*X, J*Y, K*Z) voxels.  64-bit indices (the reference's 32-bit ones wrap above
+ * 2^32 voxels, VolumeReader.h:171).  vr_disassemble_bricks is the inverse (global
+ * volume -> contiguous bricks), used to feed per-brick trees. */
+vr_status vr_assemble_bricks(const uint8_t *bricks_dev, int32_t num_bricks, const int64_t brick_dims[3],
+                             const int64_t *brick_ijk, const int64_t grid[3], uint8_t *volume_dev, void *stream);
+vr_status vr_disassemble_bricks(const uint8_t *volume_dev, int32_t num_bricks, const int64_t brick_dims[3],
+                                const int64_t *brick_ijk, const int64_t grid[3], uint8_t *bricks_dev, void *stream);
+
+/* ---- render: raycaster.frag / isosurface.frag on the UnitBrick proxy cube --------
+ * Camera = the values main.cpp feeds glm::lookAt / glm::perspectiveFov (main.cpp:33-40,396-397). */
+typedef struct vr_camera {
+    float pos[3];      /* cameraPos   (0,0,-0.75)  */
+    float front[3];    /* cameraFront (0,0,1)      */
+    float up[3];       /* cameraUp    (0,1,0)      */
+    float fov_deg;     /* fov 50                   */
+    float z_near, z_far; /* 0.1, 100               */
+} vr_camera;
+
+enum { VR_RENDER_COMPOSITE = 0 /* raycaster.frag */, VR_RENDER_ISOSURFACE = 1 /* isosurface.frag */,
+       VR_RENDER_PARTIAL = 2 /* raycaster.frag accumulation as an (rgb-premultiplied c, transmittance) pair for sort-last compositing */ };
+
+typedef struct vr_render_params {
+    int32_t width, height;   /* 1600x1200 in the reference (main.cpp:27); bench uses 1920x1080 */
+    float step_size[3];      /* uniform step_size = 1/BRICK_DIM (main.cpp:330-331)             */
+    float iso_value;         /* uniform isoValue = currIsoVal/255 (main.cpp:334)               */
+    int32_t max_samples;     /* MAX_SAMPLES = 300 (raycaster.frag:14)                          */
+    int32_t mode;            /* VR_RENDER_*                                                    */
+    /* Sort-last multi-GPU path (VR_RENDER_PARTIAL): the rank owns the samples whose texture-space
+     * position lies in [box_min, box_max); volume_dev holds the voxels [vol_origin, vol_origin+dims)
+     * of a global volume of global_dims voxels (own slab plus halo layers for filtering).
+     * Single-GPU path: box {0,0,0}-{1,1,1}, global_dims {0,0,0} (= dims), vol_origin {0,0,0}. */
+    float box_min[3], box_max[3];
+    int64_t global_dims[3];
+    int64_t vol_origin[3];
+    int32_t no_early_exit;   /* 1: ignore the alpha>0.99 exit (reference for the sort-last path)   */
+    int32_t reserved;
+} vr_render_params;
+
+/* volume_dev: X*Y*Z uint8 (the 3-D texture contents, GL_RED/GL_UNSIGNED_BYTE, GL_LINEAR,
+ * clamp-to-edge: VolumeReader.h:114-127).  rgba_dev: height*width*4 float32, row 0 = top.
+ * Pixels not covered by the cube are white (main.cpp:392). */
+vr_status vr_raycast(const uint8_t *volume_dev, const int64_t dims[3], const vr_camera *cam,
+                     const vr_render_params *params, float *rgba_dev, void *stream);
+
+/* Sort-last compositing of VR_RENDER_PARTIAL images: front = front OVER back, per pixel
+ * (c1 + t1*c2, t1*t2); and the final colour transfer of raycaster.frag:82-85. */
+vr_status vr_composite_over(float *front_dev, const float *back_dev, int64_t num_pixels, void *stream);
+vr_status vr_composite_finish(const float *partial_dev, float *rgba_dev, int64_t num_pixels, void *stream);
+
+/* ---- instrumentation (the reference's DebugTimer phases, R.cpp:47-113) ----------
+ * Milliseconds of the last build / decode measured with hipEvents on the call's stream:
+ * phases[0..4] = BUILD(pyramid), COMPRESS, PRUNE, CONVERT, DECODE. */
+vr_status vr_brickset_last_timings(vr_brickset *bs, float phases_ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRHIP_H */

@@ -65,6 +65,7 @@ typedef struct vko_tree {
     int64_t tempLen;
     byte *recon; /* leaf-level reconstruction */
     int64_t reconLen;
+    byte *reconAll; /* debugging aid: final recon of EVERY level, BFS order (not in the reference) */
     const byte *data; /* caller's voxels, x fastest (R.cpp:4-6); not owned */
     /* MidRangeTree second stream (M.cpp) */
     int32_t midrange; /* 0 = VolumeKdtree, 1 = MidRangeTree */
@@ -120,6 +121,7 @@ void vko_destroy(vko_tree *t)
     free(t->distanceMap); free(t->tree); free(t->temp); free(t->recon);
     free(t->distanceMapRange); free(t->treeRange); free(t->tempRange); free(t->reconRange);
     free(t->trace);
+    free(t->reconAll);
     free(t);
 }
 
@@ -218,7 +220,8 @@ static inline double clampd(double v, double lo, double hi) { return fmin(hi, fm
 /* R.cpp:206-384 (M.cpp:241-397 and :399-544 are the same loop on temp / temp_range).
  * truthBFS: BFS array of node truths; treeBits: BFS 2-bit codes (written);
  * distMap: per-level distance (written 0..D); reconOut: leaf-level recon (malloc'd). */
-static byte *compress_gradient_descent(vko_tree *t, const byte *truthBFS, byte *treeBits, byte *distMap)
+static byte *compress_gradient_descent(vko_tree *t, const byte *truthBFS, byte *treeBits, byte *distMap,
+                                       byte *reconAllOut)
 {
     const double gamma = 1.25, h = 1.0, maxAbsStepSize = 4.0;
     const int D = t->origTreeDepth;
@@ -312,6 +315,7 @@ static byte *compress_gradient_descent(vko_tree *t, const byte *truthBFS, byte *
             epoch++;
         }
         distMap[depth] = (byte)currentDistance; /* R.cpp:369 */
+        if (reconAllOut) memcpy(reconAllOut + startingNodeIdx, recon, (size_t)numNodes);
 
         if (depth < D) { /* R.cpp:374-381 */
             byte *tmp = parents; parents = recon; recon = tmp;
@@ -463,12 +467,13 @@ int vko_build_to_stage(vko_tree *t, int stage)
     t->treeBytes = tb_bytes(t->numOrigNodes);
     t->tree = (byte *)calloc((size_t)t->treeBytes, 1);
     t->firstOrigLeaf = ((int64_t)1 << t->origTreeDepth) - 1;
-    t->recon = compress_gradient_descent(t, t->temp, t->tree, t->distanceMap);
+    t->reconAll = (byte *)calloc((size_t)t->numOrigNodes, 1);
+    t->recon = compress_gradient_descent(t, t->temp, t->tree, t->distanceMap, t->reconAll);
     t->reconLen = (int64_t)1 << t->origTreeDepth;
     if (t->midrange) {
         t->treeRangeBytes = t->treeBytes;
         t->treeRange = (byte *)calloc((size_t)t->treeRangeBytes, 1);
-        t->reconRange = compress_gradient_descent(t, t->tempRange, t->treeRange, t->distanceMapRange);
+        t->reconRange = compress_gradient_descent(t, t->tempRange, t->treeRange, t->distanceMapRange, NULL);
     }
     /* temp.erase(begin, begin+firstOrigLeaf) R.cpp:64 */
     memmove(t->temp, t->temp + t->firstOrigLeaf, (size_t)t->reconLen);
@@ -670,6 +675,7 @@ int64_t vko_temp_len(const vko_tree *t) { return t->tempLen; }
 const byte *vko_temp_ptr(const vko_tree *t) { return t->temp; }
 int64_t vko_recon_len(const vko_tree *t) { return t->reconLen; }
 const byte *vko_recon_ptr(const vko_tree *t) { return t->recon; }
+const byte *vko_recon_all_ptr(const vko_tree *t) { return t->reconAll; }
 const byte *vko_tree_range_ptr(const vko_tree *t) { return t->treeRange; }
 int64_t vko_tree_range_bytes(const vko_tree *t) { return t->treeRangeBytes; }
 const byte *vko_distance_map_range_ptr(const vko_tree *t) { return t->distanceMapRange; }

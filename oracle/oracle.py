@@ -40,8 +40,9 @@ class RenderParams(C.Structure):
     """Mirrors vr_render_params in include/vrhip.h (main.cpp:330-334, raycaster.frag:14)."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("step_size", C.c_float * 3),
                 ("iso_value", C.c_float), ("max_samples", C.c_int32), ("mode", C.c_int32),
-                ("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("sample_offset", C.c_int32),
-                ("no_early_exit", C.c_int32)]
+                ("box_min", C.c_float * 3), ("box_max", C.c_float * 3),
+                ("global_dims", C.c_int64 * 3), ("vol_origin", C.c_int64 * 3),
+                ("no_early_exit", C.c_int32), ("reserved", C.c_int32)]
 
 
 def lib():
@@ -72,7 +73,7 @@ def lib():
                  "vko_temp_len", "vko_recon_len", "vko_tree_range_bytes"):
         getattr(L, name).argtypes = [p]
         getattr(L, name).restype = i64
-    for name in ("vko_tree_ptr", "vko_distance_map_ptr", "vko_temp_ptr", "vko_recon_ptr", "vko_tree_range_ptr",
+    for name in ("vko_tree_ptr", "vko_distance_map_ptr", "vko_temp_ptr", "vko_recon_ptr", "vko_recon_all_ptr", "vko_tree_range_ptr",
                  "vko_distance_map_range_ptr", "vko_temp_range_ptr", "vko_recon_range_ptr"):
         getattr(L, name).argtypes = [p]
         getattr(L, name).restype = u8p
@@ -94,6 +95,7 @@ def lib():
         L.vro_render.argtypes = [p, i64, i64, i64, C.POINTER(Camera), C.POINTER(RenderParams), p]
         L.vro_render.restype = C.c_int
         L.vro_composite_over.argtypes = [p, p, i64]
+        L.vro_composite_finish.argtypes = [p, p, i64]
     _lib = L
     return L
 
@@ -191,6 +193,8 @@ class OracleTree:
     @property
     def recon(self): return _u8(self._L.vko_recon_ptr(self._h), self._L.vko_recon_len(self._h))
     @property
+    def recon_all(self): return _u8(self._L.vko_recon_all_ptr(self._h), self.numOrigNodes)
+    @property
     def tree_range(self): return _u8(self._L.vko_tree_range_ptr(self._h), self._L.vko_tree_range_bytes(self._h))
     @property
     def distanceMap_range(self): return _u8(self._L.vko_distance_map_range_ptr(self._h), self.maxTreeDepth + 1)
@@ -253,3 +257,53 @@ def query_error(decoded, original):
     out = np.empty_like(a)
     lib().vko_query_error(a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data)
     return out.reshape(np.shape(decoded))
+
+
+def default_camera():
+    """main.cpp:33-40: start camera."""
+    cam = Camera()
+    cam.pos[:] = (0.0, 0.0, -0.75)
+    cam.front[:] = (0.0, 0.0, 1.0)
+    cam.up[:] = (0.0, 1.0, 0.0)
+    cam.fov_deg, cam.z_near, cam.z_far = 50.0, 0.1, 100.0
+    return cam
+
+
+def default_params(width, height, brick_dims=(256, 256, 128), mode=0, iso=40.0 / 255.0):
+    """main.cpp:330-334 uniforms; raycaster.frag:14 MAX_SAMPLES."""
+    P = RenderParams()
+    P.width, P.height = width, height
+    P.step_size[:] = tuple(1.0 / d for d in brick_dims)
+    P.iso_value = iso
+    P.max_samples = 300
+    P.mode = mode
+    P.box_min[:] = (0.0, 0.0, 0.0)
+    P.box_max[:] = (1.0, 1.0, 1.0)
+    P.global_dims[:] = (0, 0, 0)
+    P.vol_origin[:] = (0, 0, 0)
+    P.no_early_exit = 0
+    return P
+
+
+def render(volume, cam, params):
+    """volume: uint8 [Z][Y][X]; returns float32 [H][W][4], row 0 = top."""
+    v = np.ascontiguousarray(volume, np.uint8)
+    z, y, x = v.shape
+    out = np.empty((params.height, params.width, 4), np.float32)
+    rc = lib().vro_render(v.ctypes.data, x, y, z, C.byref(cam), C.byref(params), out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def composite_over(front, back):
+    f = np.ascontiguousarray(front, np.float32).copy()
+    b = np.ascontiguousarray(back, np.float32)
+    lib().vro_composite_over(f.ctypes.data, b.ctypes.data, f.size // 4)
+    return f
+
+
+def composite_finish(partial):
+    p_ = np.ascontiguousarray(partial, np.float32)
+    out = np.empty_like(p_)
+    lib().vro_composite_finish(p_.ctypes.data, out.ctypes.data, p_.size // 4)
+    return out

@@ -1,0 +1,165 @@
+"""GPU parity: the HIP encode / decode path (through the C ABI) against the CPU oracle.
+
+Bit-exact: tree bytes, distanceMap, numActiveNodes, decoded voxels."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vr():
+    import torch
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    g.build()
+    import volumerenderer_amd as vr
+    return vr
+
+
+def rm_like(shape, seed=3):
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    h = shape[0] / 2 + 3 * np.sin(x * 0.4) + 2 * np.cos(y * 0.23)
+    v = 128 + 120 * np.tanh((z - h) / 3.0) + rng.integers(0, 3, shape)
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def check_case(vr, O, vol, tol, ep, variant=0):
+    z, y, x = vol.shape
+    ref = O.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep).build()
+    bs = vr.BrickSet(1, (x, y, z), tol, ep, variant)
+    bs.build(vol.copy())
+    info = bs.info(0)
+    assert info["orig_tree_depth"] == ref.origTreeDepth and info["max_tree_depth"] == ref.maxTreeDepth
+    assert list(bs.distance_map(0)) == list(ref.distanceMap)
+    assert info["num_active_nodes"] == ref.numActiveNodes
+    assert np.array_equal(bs.tree(0), ref.tree)
+    assert info["num_reverts"] == ref.numReverts
+    st = ref.leaf_stats()
+    assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"]
+    dec = bs.decode().cpu().numpy().reshape(z, y, x)
+    assert np.array_equal(dec, ref.levelCut())
+    return ref, bs
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64])
+def test_sphere_n3_cubes(vr, oracle, n):
+    check_case(vr, oracle, oracle.gen_sphere(n, 7), 1, 2)
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 16), (16, 8, 32), (4, 64, 2), (32, 32, 16), (1, 1, 8), (1, 16, 1)])
+def test_anisotropic_bricks(vr, oracle, shape):
+    rng = np.random.default_rng(11)
+    check_case(vr, oracle, rng.integers(0, 256, shape, dtype=np.uint8), 2, 2)
+    check_case(vr, oracle, rm_like(shape), 1, 2)
+
+
+@pytest.mark.parametrize("tol", [0, 1, 2, 4, 6, 12])
+@pytest.mark.parametrize("ep", [1, 2, 5])
+def test_tolerance_epoch_sweep(vr, oracle, tol, ep):
+    rng = np.random.default_rng(tol * 10 + ep)
+    check_case(vr, oracle, rng.integers(0, 256, (16, 16, 16), dtype=np.uint8), tol, ep)
+    check_case(vr, oracle, oracle.gen_sphere(32, 3), tol, ep)
+
+
+def test_reverts_reproduced(vr, oracle):
+    """Defect C-2: stale codes after a gradient-descent revert."""
+    hit = 0
+    for seed in range(6):
+        rng = np.random.default_rng(100 + seed)
+        ref, _ = check_case(vr, oracle, rng.integers(0, 256, (32, 32, 32), dtype=np.uint8), 0, 5)
+        hit += ref.numReverts
+    ref, _ = check_case(vr, oracle, oracle.gen_sphere(128, 7), 1, 2)   # the survey's revert case
+    assert ref.numReverts >= 1
+    assert hit + ref.numReverts >= 1
+
+
+def test_degenerate_volumes(vr, oracle):
+    for v in (0, 37, 255):
+        ref, bs = check_case(vr, oracle, np.full((16, 16, 16), v, np.uint8), 1, 2)
+        assert bs.info(0)["num_active_nodes"] == (1 if v == 0 else 3)
+    check_case(vr, oracle, np.zeros((1, 1, 1), np.uint8) + 9, 1, 2)   # D = 0
+    check_case(vr, oracle, oracle.gen_sphere(16, 7), 1, 0)            # maxEpochs = 0
+
+
+def test_guarded_variant_same_bytes(vr, oracle):
+    vol = oracle.gen_sphere(32, 7)
+    a = vr.BrickSet(1, (32, 32, 32), 1, 3, 0).build(vol.copy())
+    b = vr.BrickSet(1, (32, 32, 32), 1, 3, 1).build(vol.copy())
+    assert np.array_equal(a.tree(0), b.tree(0))
+
+
+def test_batched_bricks_match_single(vr, oracle):
+    import torch
+    rng = np.random.default_rng(5)
+    vols = [oracle.gen_sphere(32, 7), rng.integers(0, 256, (32, 32, 32), dtype=np.uint8),
+            np.full((32, 32, 32), 200, np.uint8), rm_like((32, 32, 32)), oracle.gen_sphere(32, 0)]
+    bs = vr.BrickSet(len(vols), (32, 32, 32), 1, 2)
+    bs.build(np.stack(vols))
+    dec = bs.decode().cpu().numpy().reshape(len(vols), 32, 32, 32)
+    for i, v in enumerate(vols):
+        ref = oracle.OracleTree(v.copy(), tolerance=1, max_epochs=2).build()
+        assert bs.info(i)["num_active_nodes"] == ref.numActiveNodes
+        assert np.array_equal(bs.tree(i), ref.tree)
+        assert list(bs.distance_map(i)) == list(ref.distanceMap)
+        assert np.array_equal(dec[i], ref.levelCut())
+
+
+def test_golden_file_decodes_on_gpu(vr, oracle, tmp_path):
+    """open() of the tree file the REFERENCE wrote; decode == oracle; save() byte-identical."""
+    import json, os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    ka = json.load(open(os.path.join(gold, "survey_known_answers.json")))["volume_kdtree"][0]
+    t = vr.VolumeKdtree().open(os.path.join(gold, ka["saved_file"]))
+    assert t.numActiveNodes == ka["numActiveNodes"]
+    dec = t.levelCut(t.maxTreeDepth).cpu().numpy()
+    assert "%016x" % oracle.fnv1a64(dec) == ka["voxels_fnv"]
+    vol = oracle.gen_sphere(16, 7)
+    k = vr.VolumeKdtree(vol.copy(), 16, 16, 16)
+    k.setMaxEpochs(2); k.setErrorTolerance(1)
+    k.build()
+    assert "%016x" % oracle.fnv1a64(k.tree) == ka["tree_fnv"]
+    assert list(k.distanceMap) == ka["distanceMap"]
+    p = str(tmp_path / "t.bin")
+    k.save(p)
+    assert open(p, "rb").read() == open(os.path.join(gold, ka["saved_file"]), "rb").read()
+    k.levelCut(k.maxTreeDepth)
+    assert k.measureMaxError() == oracle.measure_max_error(dec.reshape(16, 16, 16), vol)
+    assert abs(k.measureMeanError() - oracle.measure_mean_error(dec.reshape(16, 16, 16), vol)) < 1e-12
+
+
+def test_midrange_tree(vr, oracle):
+    vol = oracle.gen_sphere(32, 7)
+    ref = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=1, midrange=True, guarded=True).build()
+    t = vr.MidRangeTree(vol.copy(), 32, 32, 32)
+    t.setMaxEpochs(1); t.setErrorTolerance(1)
+    t.build()
+    assert t.numActiveNodes == ref.numActiveNodes == 172562
+    assert np.array_equal(t.tree, ref.tree)
+    assert np.array_equal(t.tree_range, ref.tree_range)
+    assert list(t.distanceMap_range) == list(ref.distanceMap_range)
+    pk = t.convertToByteArray()
+    assert np.array_equal(pk, ref.convertToByteArray())
+    assert "%016x" % oracle.fnv1a64(pk) == "d363bd19dd90d0fd"     # SURVEY Appendix B known answer
+    rng = np.random.default_rng(2)
+    v2 = rng.integers(0, 256, (16, 16, 8), dtype=np.uint8)
+    r2 = oracle.OracleTree(v2.copy(), tolerance=2, max_epochs=3, midrange=True, guarded=True).build()
+    t2 = vr.MidRangeTree(v2.copy(), 8, 16, 16)
+    t2.setMaxEpochs(3); t2.setErrorTolerance(2)
+    t2.build()
+    assert np.array_equal(t2.tree, r2.tree) and np.array_equal(t2.tree_range, r2.tree_range)
+    assert np.array_equal(t2.convertToByteArray(), r2.convertToByteArray())
+
+
+@pytest.mark.parametrize("gen", ["sphere_n3", "sphere_n0", "random"])
+def test_full_brick_256(vr, oracle, gen):
+    """BASELINE config 1/2: one 256^3 brick, hashes recorded from the reference."""
+    mask = {"sphere_n3": 7, "sphere_n0": 0, "random": 256}[gen]
+    vol = oracle.gen_sphere(256, mask)
+    ref, bs = check_case(vr, oracle, vol, 1, 2)
+    if gen == "sphere_n3":
+        assert "%016x" % oracle.fnv1a64(bs.tree(0)) == "aaa282422610f044"
+        assert "%016x" % oracle.fnv1a64(bs.decode().cpu().numpy()) == "e97ae40e1e4bb47c"
+    if gen == "sphere_n0":
+        assert bs.info(0)["num_active_nodes"] == 21373869

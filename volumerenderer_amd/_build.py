@@ -1,0 +1,35 @@
+"""Builds volumerenderer_amd/libvrhip.so with hipcc for gfx950 (in-tree, no JIT cache)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvrhip.so")
+SOURCES = ["kd_encode.hip", "kd_decode.hip", "raymarch.hip", "capi.hip"]
+HEADERS = ["kd_common.h", "brickset.h", os.path.join("..", "..", "include", "vrhip.h")]
+# -ffp-contract=off: the gradient-descent control kernel and the ray marcher must round
+# exactly like the reference's scalar code (no FMA contraction).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not (force or _stale()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,58 @@
+// brickset.h -- host-side state behind the opaque vr_brickset handle.
+#pragma once
+#include "kd_common.h"
+#include <string>
+#include <vector>
+
+namespace vr {
+
+struct Stream2 {              // one 2-bit stream (mid, or MidRangeTree's half-range stream)
+    uint8_t *temp = nullptr;  // B * heapStride   truth heap (midrange / half range), 1-based
+    uint8_t *codes = nullptr; // B * heapStride   2-bit codes, one per byte, 1-based heap (BFS)
+    uint8_t *recon[3] = {nullptr, nullptr, nullptr}; // B * leafStride each: parents + two level buffers
+    Ctrl *ctrl = nullptr;     // B
+    uint8_t *tree = nullptr;  // B * treeCap      preorder stream, TwoBitArray packing
+};
+
+struct BrickSet {
+    int32_t B = 0;
+    Geom g{};
+    int32_t D = 0, maxDepth = 0;
+    int32_t tolerance = 6, maxEpochs = 5, variant = 0;
+    int32_t K = 0;            // decode index granularity: subtrees of 2^K leaves
+    int32_t Ds = 0;           // D - K
+    int64_t heapStride = 0;   // 2^(D+1)
+    int64_t leafStride = 0;   // 2^D
+    int64_t treeCap = 0;      // bytes per brick reserved for the preorder stream
+    int64_t nIdx = 0;         // 2^Ds index entries per brick
+
+    Stream2 mid, rng;
+    uint8_t *mmMin[2] = {nullptr, nullptr}, *mmMax[2] = {nullptr, nullptr}; // pyramid carry arrays
+    unsigned long long *blockErr = nullptr; // B * nErrBlk : per-block sum err^2 of the fill pass
+    int64_t nErrBlk = 0;
+    uint32_t *blockTot = nullptr, *blockOff = nullptr; // B * nEmitBlk
+    int64_t nEmitBlk = 0;
+    uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)
+    uint8_t *idxVal = nullptr;  // B * nIdx  decoded scalar of that root (or of the pruned ancestor)
+    uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
+
+    std::vector<Ctrl> hostCtrl; // copied back lazily
+    bool built = false, hostCtrlValid = false;
+    bool foreign = false;       // stream installed by set_tree/open (no encoder state)
+    std::vector<int64_t> openTreeBytes; // per brick: tree.bits size as the reference's open() would have it
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float phasesMs[5] = {0, 0, 0, 0, 0};
+    bool timingsPending = false, decodeTimingPending = false;
+    void *lastStream = nullptr;
+};
+
+// kd_encode.hip
+int encode_launch(BrickSet *bs, const uint8_t *voxDev, hipStream_t st);
+// kd_decode.hip
+int decode_launch(BrickSet *bs, uint8_t *outDev, hipStream_t st);
+int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *treeHost, int64_t numActive,
+                            const uint8_t *dmapHost, std::vector<uint32_t> &offs, std::vector<uint8_t> &vals);
+void make_geom(Geom &g, const int64_t dims[3]);
+void make_lut(const Geom &g, int K, std::vector<uint32_t> &lut);
+
+} // namespace vr

@@ -1,0 +1,529 @@
+// capi.hip -- the extern "C" boundary declared in include/vrhip.h.  Thin: argument
+// checks, device memory management, launches (kd_encode/kd_decode/raymarch.hip) and
+// the reference's file format.  No CPU compute path exists behind these entry points.
+#include "../../include/vrhip.h"
+#include "brickset.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+using namespace vr;
+
+namespace vr {
+int raycast_launch(const uint8_t *, const int64_t dims[3], const vr_camera *, const vr_render_params *, float *, hipStream_t);
+int composite_over_launch(float *, const float *, int64_t, hipStream_t);
+int composite_finish_launch(const float *, float *, int64_t, hipStream_t);
+int assemble_launch(bool, const uint8_t *, uint8_t *, int, const int64_t bd[3], const int64_t *, const int64_t grid[3], hipStream_t);
+int measure_error_launch(const uint8_t *, const uint8_t *, int64_t, int *, unsigned long long *, hipStream_t);
+int query_error_launch(const uint8_t *, const uint8_t *, int64_t, uint8_t *, hipStream_t);
+}
+
+struct vr_brickset { BrickSet s; };
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_ == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_NO_DEVICE; } while (0)
+
+static bool device_ok()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+extern "C" {
+
+vr_status vr_device_count(int32_t *count)
+{
+    if (!count) return VR_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return VR_OK;
+}
+
+vr_status vr_set_device(int32_t device)
+{
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    return VR_OK;
+}
+
+const char *vr_status_string(vr_status s)
+{
+    switch (s) {
+    case VR_OK: return "ok";
+    case VR_ERR_INVALID: return "invalid argument";
+    case VR_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case VR_ERR_OOM: return "out of device memory";
+    case VR_ERR_IO: return "file error";
+    case VR_ERR_STATE: return "wrong state (no tree built / loaded)";
+    case VR_ERR_FORMAT: return "malformed tree stream";
+    case VR_ERR_UNSUPPORTED: return "unsupported dimensions or option";
+    default: return "unknown";
+    }
+}
+
+const char *vr_version(void) { return "vrhip 0.1 (gfx950)"; }
+
+static void free_stream2(Stream2 &s)
+{
+    hipFree(s.temp); hipFree(s.codes);
+    for (int i = 0; i < 3; ++i) hipFree(s.recon[i]);
+    hipFree(s.ctrl); hipFree(s.tree);
+    s = Stream2();
+}
+
+static vr_status alloc_stream2(BrickSet &b, Stream2 &s, bool encoder)
+{
+    const size_t B = (size_t)b.B;
+    HIPCHK(hipMalloc(&s.ctrl, B * sizeof(Ctrl)));
+    HIPCHK(hipMemset(s.ctrl, 0, B * sizeof(Ctrl)));
+    HIPCHK(hipMalloc(&s.tree, B * (size_t)b.treeCap));
+    if (encoder) {
+        HIPCHK(hipMalloc(&s.temp, B * (size_t)b.heapStride));
+        HIPCHK(hipMalloc(&s.codes, B * (size_t)b.heapStride));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&s.recon[i], B * (size_t)b.leafStride));
+    }
+    return VR_OK;
+}
+
+static vr_status ensure_encoder_buffers(BrickSet &b)
+{
+    if (b.mid.temp) return VR_OK;
+    const size_t B = (size_t)b.B;
+    HIPCHK(hipMalloc(&b.mid.temp, B * (size_t)b.heapStride));
+    HIPCHK(hipMalloc(&b.mid.codes, B * (size_t)b.heapStride));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.mid.recon[i], B * (size_t)b.leafStride));
+    if (b.variant == VR_VARIANT_MIDRANGE) {
+        HIPCHK(hipMalloc(&b.rng.ctrl, B * sizeof(Ctrl)));
+        HIPCHK(hipMalloc(&b.rng.tree, B * (size_t)b.treeCap));
+        HIPCHK(hipMalloc(&b.rng.temp, B * (size_t)b.heapStride));
+        HIPCHK(hipMalloc(&b.rng.codes, B * (size_t)b.heapStride));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.rng.recon[i], B * (size_t)b.leafStride));
+    }
+    const int64_t mm = (int64_t)1 << (b.D > 10 ? b.D - 10 : 0);
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipMalloc(&b.mmMin[i], B * (size_t)mm));
+        HIPCHK(hipMalloc(&b.mmMax[i], B * (size_t)mm));
+    }
+    b.nErrBlk = ((int64_t)1 << b.D) / 1024 > 0 ? ((int64_t)1 << b.D) / 1024 : 1;
+    HIPCHK(hipMalloc(&b.blockErr, B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
+    b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256;
+    HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
+    return VR_OK;
+}
+
+vr_status vr_brickset_destroy(vr_brickset *h)
+{
+    if (!h) return VR_OK;
+    BrickSet &b = h->s;
+    free_stream2(b.mid);
+    free_stream2(b.rng);
+    for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
+    hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff);
+    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.lut);
+    for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
+    delete h;
+    return VR_OK;
+}
+
+static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_t dims[3], int32_t tolerance,
+                             int32_t max_epochs, int32_t variant)
+{
+    if (!out || !dims || num_bricks <= 0) return VR_ERR_INVALID;
+    if (tolerance < 0 || max_epochs < 0 || variant < 0 || variant > 2) return VR_ERR_INVALID;
+    for (int k = 0; k < 3; ++k) if (dims[k] <= 0) return VR_ERR_INVALID;
+    if (!pow2(dims[0]) || !pow2(dims[1]) || !pow2(dims[2])) return VR_ERR_UNSUPPORTED;
+    if (dims[0] > 1024 || dims[1] > 1024 || dims[2] > 1024) return VR_ERR_UNSUPPORTED;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    vr_brickset *h = new (std::nothrow) vr_brickset();
+    if (!h) return VR_ERR_OOM;
+    BrickSet &b = h->s;
+    b.B = num_bricks;
+    make_geom(b.g, dims);
+    b.D = b.g.D;
+    if (b.D > 28) { delete h; return VR_ERR_UNSUPPORTED; }
+    b.maxDepth = b.D + VR_CHAIN_LEVELS;
+    b.tolerance = tolerance; b.maxEpochs = max_epochs; b.variant = variant;
+    b.K = b.D < 9 ? b.D : 9;
+    b.Ds = b.D - b.K;
+    b.heapStride = (int64_t)1 << (b.D + 1);
+    b.leafStride = (int64_t)1 << b.D;
+    const int64_t numMax = b.heapStride - 1 + VR_CHAIN_LEVELS * b.leafStride; // numMaxNodes R.cpp:35
+    b.treeCap = ((numMax + 15) / 16 + 2) * 4;
+    b.nIdx = (int64_t)1 << b.Ds;
+    vr_status rc = alloc_stream2(b, b.mid, false);
+    if (rc == VR_OK) {
+        hipError_t e = hipMalloc(&b.idxOff, (size_t)b.B * b.nIdx * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&b.idxVal, (size_t)b.B * b.nIdx);
+        if (e == hipSuccess) e = hipMalloc(&b.lut, ((size_t)1 << b.K) * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            std::vector<uint32_t> lut;
+            make_lut(b.g, b.K, lut);
+            e = hipMemcpy(b.lut, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        }
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&b.ev[i]);
+        if (e != hipSuccess) rc = e == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
+    }
+    if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }
+    b.hostCtrl.resize(b.B);
+    b.openTreeBytes.assign(b.B, -1);
+    *out = h;
+    return VR_OK;
+}
+
+vr_status vr_brickset_set_error_tolerance(vr_brickset *h, int32_t tol)
+{
+    if (!h || tol < 0) return VR_ERR_INVALID;
+    h->s.tolerance = tol;
+    return VR_OK;
+}
+vr_status vr_brickset_set_max_epochs(vr_brickset *h, int32_t e)
+{
+    if (!h || e < 0) return VR_ERR_INVALID;
+    h->s.maxEpochs = e;
+    return VR_OK;
+}
+
+vr_status vr_brickset_build(vr_brickset *h, const uint8_t *vox, void *stream)
+{
+    if (!h || !vox) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    vr_status rc = ensure_encoder_buffers(b);
+    if (rc != VR_OK) return rc;
+    b.hostCtrlValid = false;
+    b.foreign = false;
+    std::fill(b.openTreeBytes.begin(), b.openTreeBytes.end(), -1);
+    if (encode_launch(&b, vox, (hipStream_t)stream) != 0) return VR_ERR_NO_DEVICE;
+    b.built = true;
+    b.timingsPending = true;
+    b.lastStream = stream;
+    return VR_OK;
+}
+
+static vr_status sync_ctrl(BrickSet &b)
+{
+    if (!b.built) return VR_ERR_STATE;
+    if (b.hostCtrlValid) return VR_OK;
+    HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
+    HIPCHK(hipMemcpy(b.hostCtrl.data(), b.mid.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
+    b.hostCtrlValid = true;
+    return VR_OK;
+}
+
+vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
+{
+    if (!h || !info || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    vr_status rc = sync_ctrl(b);
+    if (rc != VR_OK) return rc;
+    const Ctrl &c = b.hostCtrl[brick];
+    memset(info, 0, sizeof(*info));
+    info->X = b.g.X; info->Y = b.g.Y; info->Z = b.g.Z;
+    info->orig_tree_depth = b.D;
+    info->max_tree_depth = b.maxDepth;
+    info->num_active_nodes = (int64_t)c.numActive;
+    info->tree_bytes = ((int64_t)c.numActive + 3) / 4;
+    info->tolerance = b.tolerance; info->max_epochs = b.maxEpochs; info->variant = b.variant;
+    info->num_reverts = c.numReverts;
+    info->max_error_before = c.maxErrBefore;
+    info->max_error_after = c.maxErrAfter;
+    info->mean_l1_after = (double)c.statL1 / (double)b.leafStride;
+    return VR_OK;
+}
+
+static vr_status get_tree_common(BrickSet &b, Stream2 &s, int brick, uint8_t *dst, int64_t cap)
+{
+    vr_status rc = sync_ctrl(b);
+    if (rc != VR_OK) return rc;
+    int64_t bytes = ((int64_t)b.hostCtrl[brick].numActive + 3) / 4;
+    if (!dst || cap < bytes) return VR_ERR_INVALID;
+    if (!s.tree) return VR_ERR_STATE;
+    HIPCHK(hipMemcpy(dst, s.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    return VR_OK;
+}
+
+vr_status vr_brickset_get_tree(vr_brickset *h, int32_t brick, uint8_t *dst, int64_t cap)
+{
+    if (!h || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    return get_tree_common(h->s, h->s.mid, brick, dst, cap);
+}
+
+vr_status vr_brickset_get_distance_map(vr_brickset *h, int32_t brick, uint8_t *dst, int32_t cap)
+{
+    if (!h || !dst || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    vr_status rc = sync_ctrl(b);
+    if (rc != VR_OK) return rc;
+    if (cap < b.maxDepth + 1) return VR_ERR_INVALID;
+    memcpy(dst, b.hostCtrl[brick].distanceMap, (size_t)b.maxDepth + 1);
+    return VR_OK;
+}
+
+vr_status vr_brickset_get_tree_range(vr_brickset *h, int32_t brick, uint8_t *dst, int64_t cap)
+{
+    if (!h || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    if (h->s.variant != VR_VARIANT_MIDRANGE || h->s.foreign) return VR_ERR_STATE;
+    return get_tree_common(h->s, h->s.rng, brick, dst, cap);
+}
+
+vr_status vr_brickset_get_distance_map_range(vr_brickset *h, int32_t brick, uint8_t *dst, int32_t cap)
+{
+    if (!h || !dst || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    if (b.variant != VR_VARIANT_MIDRANGE || b.foreign) return VR_ERR_STATE;
+    vr_status rc = sync_ctrl(b);
+    if (rc != VR_OK) return rc;
+    if (cap < b.maxDepth + 1) return VR_ERR_INVALID;
+    Ctrl c;
+    HIPCHK(hipMemcpy(&c, b.rng.ctrl + brick, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    memcpy(dst, c.distanceMap, (size_t)b.maxDepth + 1);
+    return VR_OK;
+}
+
+// M.cpp:1095-1128 convertToByteArray.  A byte-shuffle of two host-visible streams:
+// done on the host from the bytes the GPU encoder produced (format conversion, not
+// part of the compute path).
+vr_status vr_brickset_get_packed4(vr_brickset *h, int32_t brick, uint8_t *dst, int64_t cap, int64_t *length)
+{
+    if (!h || !length || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    if (b.variant != VR_VARIANT_MIDRANGE || b.foreign) return VR_ERR_STATE;
+    vr_status rc = sync_ctrl(b);
+    if (rc != VR_OK) return rc;
+    const int64_t n = (int64_t)b.hostCtrl[brick].numActive;
+    int64_t v = (int64_t)ceil((double)n / 2.0);
+    v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++;
+    *length = v;
+    if (!dst) return VR_OK;
+    if (cap < v) return VR_ERR_INVALID;
+    const int64_t bytes = (n + 3) / 4;
+    std::vector<uint8_t> m((size_t)bytes), r((size_t)bytes);
+    HIPCHK(hipMemcpy(m.data(), b.mid.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r.data(), b.rng.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    memset(dst, 0, (size_t)v);
+    auto get = [](const std::vector<uint8_t> &a, int64_t i) { return (a[(size_t)(i >> 2)] >> ((i & 3) * 2)) & 3; };
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; i += 2) {
+        int first = get(m, i), second = get(r, i), third = 0, fourth = 0;
+        if (i + 1 < n) { third = get(m, i + 1); fourth = get(r, i + 1); }
+        dst[o++] = (uint8_t)((first << 6) | (second << 4) | (third << 2) | fourth);
+    }
+    return VR_OK;
+}
+
+vr_status vr_brickset_decode(vr_brickset *h, int32_t cut_depth, uint8_t *out, void *stream)
+{
+    if (!h || !out) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    if (!b.built) return VR_ERR_STATE;
+    if (cut_depth >= 0 && cut_depth != b.maxDepth) return VR_ERR_UNSUPPORTED; // SURVEY C-4
+    if (decode_launch(&b, out, (hipStream_t)stream) != 0) return VR_ERR_NO_DEVICE;
+    b.decodeTimingPending = true;
+    b.lastStream = stream;
+    return VR_OK;
+}
+
+vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tree, int64_t tree_bytes,
+                               int64_t num_active, const uint8_t *dmap, int32_t map_len)
+{
+    if (!h || !tree || !dmap || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    if (map_len < b.maxDepth + 1 || num_active <= 0) return VR_ERR_INVALID;
+    const int64_t need = (num_active + 3) / 4;
+    if (tree_bytes < need || need > b.treeCap) return VR_ERR_FORMAT;
+    std::vector<uint32_t> offs;
+    std::vector<uint8_t> vals;
+    if (build_index_from_stream(&b, brick, tree, num_active, dmap, offs, vals) != 0) return VR_ERR_FORMAT;
+    if (!b.built) { // first foreign tree: other bricks stay empty until set
+        HIPCHK(hipMemset(b.mid.ctrl, 0, (size_t)b.B * sizeof(Ctrl)));
+        std::vector<uint32_t> dead((size_t)b.B * b.nIdx, VR_IDX_DEAD);
+        HIPCHK(hipMemcpy(b.idxOff, dead.data(), dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(b.idxVal, 0, (size_t)b.B * b.nIdx));
+        for (auto &c : b.hostCtrl) memset(&c, 0, sizeof(Ctrl));
+    } else {
+        vr_status rc = sync_ctrl(b);
+        if (rc != VR_OK) return rc;
+    }
+    Ctrl &c = b.hostCtrl[brick];
+    memset(&c, 0, sizeof(Ctrl));
+    c.numActive = (unsigned long long)num_active;
+    memcpy(c.distanceMap, dmap, (size_t)b.maxDepth + 1);
+    HIPCHK(hipMemcpy(b.mid.ctrl + brick, &c, sizeof(Ctrl), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(b.mid.tree + (size_t)brick * b.treeCap, 0, (size_t)b.treeCap));
+    HIPCHK(hipMemcpy(b.mid.tree + (size_t)brick * b.treeCap, tree, (size_t)need, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b.idxOff + (size_t)brick * b.nIdx, offs.data(), offs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b.idxVal + (size_t)brick * b.nIdx, vals.data(), vals.size(), hipMemcpyHostToDevice));
+    b.built = true;
+    b.hostCtrlValid = true;
+    b.foreign = true;
+    return VR_OK;
+}
+
+// File layout of VolumeKdtree::save (R.cpp:535-544).
+vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
+{
+    if (!h || !path || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    vr_status rc = sync_ctrl(b);
+    if (rc != VR_OK) return rc;                       // "ERROR! No tree to save." R.cpp:526-530
+    const Ctrl &c = b.hostCtrl[brick];
+    const int64_t bytes = ((int64_t)c.numActive + 3) / 4;
+    if (bytes == 0) return VR_ERR_STATE;
+    std::vector<uint8_t> tree((size_t)bytes);
+    HIPCHK(hipMemcpy(tree.data(), b.mid.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    FILE *f = fopen(path, "wb");
+    if (!f) return VR_ERR_IO;
+    int64_t rootMin[3] = {0, 0, 0}, rootMax[3] = {b.g.X, b.g.Y, b.g.Z};
+    int32_t mtd = b.maxDepth, otd = b.D;
+    int64_t X = b.g.X, Y = b.g.Y, Z = b.g.Z, na = (int64_t)c.numActive;
+    bool ok = fwrite(rootMin, 8, 3, f) == 3 && fwrite(rootMax, 8, 3, f) == 3 && fwrite(&mtd, 4, 1, f) == 1 &&
+              fwrite(&otd, 4, 1, f) == 1 && fwrite(&X, 8, 1, f) == 1 && fwrite(&Y, 8, 1, f) == 1 &&
+              fwrite(&Z, 8, 1, f) == 1 && fwrite(&na, 8, 1, f) == 1 &&
+              fwrite(c.distanceMap, 1, (size_t)mtd + 1, f) == (size_t)mtd + 1 &&
+              fwrite(tree.data(), 1, (size_t)bytes, f) == (size_t)bytes;
+    fclose(f);
+    return ok ? VR_OK : VR_ERR_IO;
+}
+
+// VolumeKdtree::open (R.cpp:554-594).  A missing file is an error code here (the
+// reference waits for Enter and calls exit(-1)).
+vr_status vr_brickset_open(vr_brickset **out, const char *path)
+{
+    if (!out || !path) return VR_ERR_INVALID;
+    FILE *f = fopen(path, "rb");
+    if (!f) return VR_ERR_IO;
+    fseek(f, 0, SEEK_END);
+    const int64_t fileSize = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    int64_t rootMin[3], rootMax[3], X, Y, Z, na;
+    int32_t mtd, otd;
+    bool ok = fread(rootMin, 8, 3, f) == 3 && fread(rootMax, 8, 3, f) == 3 && fread(&mtd, 4, 1, f) == 1 &&
+              fread(&otd, 4, 1, f) == 1 && fread(&X, 8, 1, f) == 1 && fread(&Y, 8, 1, f) == 1 &&
+              fread(&Z, 8, 1, f) == 1 && fread(&na, 8, 1, f) == 1;
+    if (!ok || mtd < VR_CHAIN_LEVELS || mtd >= VR_MAX_DEPTH || na <= 0) { fclose(f); return VR_ERR_FORMAT; }
+    std::vector<uint8_t> dmap((size_t)mtd + 1);
+    // R.cpp:581 subtracts only three of the four int64 fields: tree.bits ends up 8 bytes
+    // longer than what was saved (SURVEY C-6); numActiveNodes is authoritative.
+    const int64_t openBytes = fileSize - (2 * 24 + 2 * 4 + mtd + 1 + 3 * 8);
+    const int64_t have = fileSize - (88 + mtd + 1);
+    if (have < (na + 3) / 4) { fclose(f); return VR_ERR_FORMAT; }
+    std::vector<uint8_t> tree((size_t)have);
+    ok = fread(dmap.data(), 1, dmap.size(), f) == dmap.size() && fread(tree.data(), 1, tree.size(), f) == tree.size();
+    fclose(f);
+    if (!ok) return VR_ERR_IO;
+    int64_t dims[3] = {X, Y, Z};
+    vr_brickset *h = nullptr;
+    vr_status rc = vr_brickset_create(&h, 1, dims, 6, 5, VR_VARIANT_RECOVER); // ctor defaults R.h:89-94
+    if (rc != VR_OK) return rc;
+    if (h->s.D != otd || h->s.maxDepth != mtd) { vr_brickset_destroy(h); return VR_ERR_FORMAT; }
+    rc = vr_brickset_set_tree(h, 0, tree.data(), (int64_t)tree.size(), na, dmap.data(), mtd + 1);
+    if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }
+    h->s.openTreeBytes[0] = openBytes;
+    *out = h;
+    return VR_OK;
+}
+
+vr_status vr_measure_error(const uint8_t *dec, const uint8_t *orig, int64_t n, int32_t *max_error, double *mean_error,
+                           void *stream)
+{
+    if (!dec || !orig || n <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    int *dMax = nullptr;
+    unsigned long long *dSum = nullptr;
+    HIPCHK(hipMalloc(&dMax, sizeof(int)));
+    HIPCHK(hipMalloc(&dSum, sizeof(unsigned long long)));
+    hipMemsetAsync(dMax, 0, sizeof(int), (hipStream_t)stream);
+    hipMemsetAsync(dSum, 0, sizeof(unsigned long long), (hipStream_t)stream);
+    int rc = measure_error_launch(dec, orig, n, dMax, dSum, (hipStream_t)stream);
+    int hm = 0;
+    unsigned long long hs = 0;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpy(&hm, dMax, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&hs, dSum, sizeof(hs), hipMemcpyDeviceToHost);
+    hipFree(dMax); hipFree(dSum);
+    if (rc != 0 || e != hipSuccess) return VR_ERR_NO_DEVICE;
+    if (max_error) *max_error = hm;
+    if (mean_error) *mean_error = (double)hs / (double)n;
+    return VR_OK;
+}
+
+vr_status vr_query_error(const uint8_t *dec, const uint8_t *orig, int64_t n, uint8_t *err, void *stream)
+{
+    if (!dec || !orig || !err || n <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    return query_error_launch(dec, orig, n, err, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+static vr_status assemble_common(bool toVolume, const uint8_t *src, int32_t nb, const int64_t bd[3], const int64_t *ijk,
+                                 const int64_t grid[3], uint8_t *dst, void *stream)
+{
+    if (!src || !dst || !bd || !ijk || !grid || nb <= 0) return VR_ERR_INVALID;
+    if (bd[0] % 16 != 0) return VR_ERR_UNSUPPORTED;
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < 3; ++k)
+            if (ijk[3 * b + k] < 0 || ijk[3 * b + k] >= grid[k]) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    int64_t *d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)nb * 3 * sizeof(int64_t)));
+    hipError_t e = hipMemcpyAsync(d, ijk, (size_t)nb * 3 * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream);
+    int rc = e == hipSuccess ? assemble_launch(toVolume, src, dst, nb, bd, d, grid, (hipStream_t)stream) : -1;
+    hipStreamSynchronize((hipStream_t)stream);
+    hipFree(d);
+    return rc == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+vr_status vr_assemble_bricks(const uint8_t *bricks, int32_t nb, const int64_t bd[3], const int64_t *ijk,
+                             const int64_t grid[3], uint8_t *volume, void *stream)
+{
+    return assemble_common(true, bricks, nb, bd, ijk, grid, volume, stream);
+}
+vr_status vr_disassemble_bricks(const uint8_t *volume, int32_t nb, const int64_t bd[3], const int64_t *ijk,
+                                const int64_t grid[3], uint8_t *bricks, void *stream)
+{
+    return assemble_common(false, volume, nb, bd, ijk, grid, bricks, stream);
+}
+
+vr_status vr_raycast(const uint8_t *vol, const int64_t dims[3], const vr_camera *cam, const vr_render_params *P,
+                     float *rgba, void *stream)
+{
+    if (!vol || !dims || !cam || !P || !rgba) return VR_ERR_INVALID;
+    if (P->width <= 0 || P->height <= 0 || P->max_samples < 0 || P->mode < 0 || P->mode > 2) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    return raycast_launch(vol, dims, cam, P, rgba, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+vr_status vr_composite_over(float *front, const float *back, int64_t n, void *stream)
+{
+    if (!front || !back || n <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    return composite_over_launch(front, back, n, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+vr_status vr_composite_finish(const float *partial, float *rgba, int64_t n, void *stream)
+{
+    if (!partial || !rgba || n <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    return composite_finish_launch(partial, rgba, n, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+vr_status vr_brickset_last_timings(vr_brickset *h, float ms[5])
+{
+    if (!h || !ms) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    if (b.timingsPending) {
+        HIPCHK(hipEventSynchronize(b.ev[4]));
+        for (int i = 0; i < 4; ++i) hipEventElapsedTime(&b.phasesMs[i], b.ev[i], b.ev[i + 1]);
+        b.timingsPending = false;
+    }
+    if (b.decodeTimingPending) {
+        HIPCHK(hipEventSynchronize(b.ev[6]));
+        hipEventElapsedTime(&b.phasesMs[4], b.ev[5], b.ev[6]);
+        b.decodeTimingPending = false;
+    }
+    for (int i = 0; i < 5; ++i) ms[i] = b.phasesMs[i];
+    return VR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,87 @@
+// kd_common.h -- shared types for the gfx950 kd-tree codec kernels.
+//
+// Layout conventions (per brick; a brickset holds B bricks back to back):
+//  * voxels       X*Y*Z uint8, x fastest (reference R.cpp:4-6).
+//  * heap arrays  1-based implicit binary heap: node at depth d with path p
+//                 (p = Morton prefix, left = 0) lives at index (1<<d) + p, so every
+//                 level starts on a power-of-two boundary.  The reference's 0-based
+//                 breadth-first index (R.cpp:176-177) is ours minus one.
+//  * leaf rank r  path of a depth-D node = the MSB-first interleave of the voxel's
+//                 coordinate bits in the reference's split-axis order (R.cpp:151-159).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VR_MAX_DEPTH 40     // origTreeDepth + 7 must stay below this
+#define VR_CHAIN_LEVELS 7   // maxAddLevels (R.cpp:22)
+#define VR_IDX_DEAD 0xFFFFFFFFu
+
+namespace vr {
+
+// Split geometry of one brick (power-of-two extents).  Passed to kernels by value.
+struct Geom {
+    int32_t D;                  // origTreeDepth
+    int32_t nb[3];              // log2 of X, Y, Z
+    int32_t X, Y, Z;
+    uint8_t axis[32];           // split axis at depth d (d < D)
+    uint8_t bit[32];            // coordinate bit decided at depth d
+    int64_t voxels;             // X*Y*Z
+};
+
+// rank (D bits, MSB = depth 0) -> voxel coordinates
+__host__ __device__ inline void rank_to_xyz(const Geom &g, uint32_t r, int &x, int &y, int &z)
+{
+    int c[3] = {0, 0, 0};
+    for (int d = 0; d < g.D; ++d) {
+        uint32_t b = (r >> (g.D - 1 - d)) & 1u;
+        c[g.axis[d]] |= (int)(b << g.bit[d]);
+    }
+    x = c[0]; y = c[1]; z = c[2];
+}
+
+// Per-brick gradient-descent state (R.cpp:215-227), lives in device memory.
+struct Ctrl {
+    double currentDistance, currentError, currentDF, currentStepSize;
+    double previousDistance, previousError, previousDF, previousStepSize;
+    unsigned long long errMinus, errPlus;   // sum err^2 at current-1 / current+1 (exact integers)
+    unsigned long long statL1;              // sum |recon-temp| over leaves after branch growth
+    unsigned long long numActive;           // numActiveNodes
+    int32_t epoch;
+    int32_t active;          // the GD loop of this level is still running
+    int32_t fillThisEpoch;   // the next fill kernel must run
+    int32_t cur, prev, pendingEqual;   // roles of the two level-recon buffers (see kd_encode.hip)
+    int32_t par, ra, rb;     // physical recon buffer indices: parents, level buffers
+    int32_t numReverts;
+    int32_t maxErrBefore, maxErrAfter;
+    int32_t pad;
+    uint8_t distanceMap[VR_MAX_DEPTH + 8];
+};
+
+// integer form of encodeNode (R.cpp:457-502): ties keep > add > sub.
+struct Enc { int code, recon, err; };
+__host__ __device__ inline Enc encode_node(int t, int p, int d)
+{
+    int none = p > t ? p - t : t - p;
+    int add = p + d > 255 ? 255 : p + d;
+    int ae = add > t ? add - t : t - add;
+    int sub = p - d < 0 ? 0 : p - d;
+    int se = sub > t ? sub - t : t - sub;
+    int m = none < ae ? none : ae;
+    m = se < m ? se : m;
+    Enc e;
+    e.err = m;
+    if (m == none) { e.code = 0; e.recon = p; }
+    else if (m == ae) { e.code = 1; e.recon = add; }
+    else { e.code = 2; e.recon = sub; }
+    return e;
+}
+
+// decoder step (R.cpp:783-787): child scalar from parent scalar and the child's code
+__host__ __device__ inline int apply_code(int v, int code, int dist)
+{
+    if (code == 1) { v += dist; return v > 255 ? 255 : v; }
+    if (code == 2) { v -= dist; return v < 0 ? 0 : v; }
+    return v;
+}
+
+} // namespace vr

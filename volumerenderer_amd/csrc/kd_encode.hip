@@ -1,0 +1,726 @@
+// kd_encode.hip -- gfx950 kernels for VolumeKdtree::build (reference
+// volume_renderer/VolumeKdTree_recover.cpp:17-140, "R.cpp").  Batched over the
+// bricks of a brickset: blockIdx.y (or blockIdx.x for per-brick control kernels)
+// selects the brick.  No MFMA: this is byte/integer work bound by HBM and, for the
+// running-mean estimator, by a true sequential dependency.
+//
+// Stages
+//   pyramid   R.cpp:143-201  bottom-up min/max -> midrange heap `temp`
+//   compress  R.cpp:206-384  per level: serial running-mean start distance,
+//                            <= maxEpochs clamped gradient-descent epochs; the GD
+//                            control flow runs on the device (k_control) so the
+//                            whole build is one launch sequence without host syncs
+//   prune     R.cpp:596-629  bottom-up, level synchronous (race free, == serial)
+//   convert   R.cpp:631-724  preorder emission by a prefix sum over leaf ranks:
+//                            leaf rank r owns the tokens of the live internal
+//                            nodes whose first leaf is r, then its own leaf token
+//                            and grown chain
+#include "brickset.h"
+#include <math.h>
+
+namespace vr {
+
+#define FILL_NODES_PER_BLOCK 1024
+#define EMIT_RANKS_PER_BLOCK 256
+
+// ---------------------------------------------------------------- pyramid ----
+// One block reduces 2^L inputs (L <= 10) at depth dLeaf and writes the midranges of
+// depths dLeaf-1 .. dLeaf-L; the block root's (min,max) goes to outMin/outMax so the
+// next round can continue upwards.  FROM_VOXELS gathers voxels in Morton order and
+// also writes the leaf level.
+template <bool FROM_VOXELS>
+__global__ void __launch_bounds__(256)
+k_pyramid(Geom g, int dLeaf, int L, const uint8_t *__restrict__ vox, const uint8_t *__restrict__ inMin,
+          const uint8_t *__restrict__ inMax, int64_t inStride, uint8_t *__restrict__ temp, int64_t heapStride,
+          uint8_t *__restrict__ tempRange, uint8_t *__restrict__ outMin, uint8_t *__restrict__ outMax,
+          int64_t outStride)
+{
+    __shared__ uint8_t smn[2][1024], smx[2][1024];
+    const int brick = blockIdx.y;
+    const uint32_t n = 1u << L;
+    const uint32_t base = blockIdx.x << L;
+    uint8_t *T = temp + (int64_t)brick * heapStride;
+    uint8_t *TR = tempRange ? tempRange + (int64_t)brick * heapStride : nullptr;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t r = base + i;
+        uint8_t mn, mx;
+        if (FROM_VOXELS) {
+            int x, y, z;
+            rank_to_xyz(g, r, x, y, z);
+            uint8_t v = vox[(int64_t)brick * g.voxels + x + (int64_t)g.X * (y + (int64_t)g.Y * z)];
+            mn = mx = v;
+            T[((int64_t)1 << dLeaf) + r] = v;       // leaf: (v+v)/2 = v  (R.cpp:194-198)
+            if (TR) TR[((int64_t)1 << dLeaf) + r] = 0; // half range of a single voxel (M.cpp:235)
+        } else {
+            mn = inMin[(int64_t)brick * inStride + r];
+            mx = inMax[(int64_t)brick * inStride + r];
+        }
+        smn[0][i] = mn;
+        smx[0][i] = mx;
+    }
+    __syncthreads();
+    for (int l = 1; l <= L; ++l) {
+        const uint32_t m = n >> l;
+        const int src = (l - 1) & 1, dst = l & 1;
+        const int da = dLeaf - l;
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+            uint8_t a = smn[src][2 * i], b = smn[src][2 * i + 1];
+            uint8_t c = smx[src][2 * i], d = smx[src][2 * i + 1];
+            uint8_t mn = a < b ? a : b, mx = c > d ? c : d;
+            smn[dst][i] = mn;
+            smx[dst][i] = mx;
+            int64_t idx = ((int64_t)1 << da) + (base >> l) + i;
+            T[idx] = (uint8_t)(((int)mx + (int)mn) >> 1);      // (byte)((max+min)/2.0) R.cpp:198
+            if (TR) TR[idx] = (uint8_t)(((int)mx - (int)mn) >> 1); // M.cpp:235
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        outMin[(int64_t)brick * outStride + blockIdx.x] = smn[L & 1][0];
+        outMax[(int64_t)brick * outStride + blockIdx.x] = smx[L & 1][0];
+    }
+}
+
+// --------------------------------------------------------------- compress ----
+struct ReconBufs { uint8_t *b[3]; };
+
+__device__ inline int phys_buf(const Ctrl &c, int role) { return role == 0 ? c.ra : c.rb; }
+
+__global__ void k_ctrl_init(Ctrl *ctrls)
+{
+    Ctrl &c = ctrls[blockIdx.x];
+    if (threadIdx.x) return;
+    c.currentDistance = c.currentError = c.currentDF = c.currentStepSize = 0.0; // defect C-1 pinned to zero
+    c.previousDistance = c.previousError = c.previousDF = c.previousStepSize = 0.0;
+    c.errMinus = c.errPlus = 0;
+    c.statL1 = 0;
+    c.numActive = 0;
+    c.epoch = 0; c.active = 0; c.fillThisEpoch = 0;
+    c.cur = 0; c.prev = 1; c.pendingEqual = 0;
+    c.par = 0; c.ra = 1; c.rb = 2;
+    c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0;
+    for (int i = 0; i < VR_MAX_DEPTH + 8; ++i) c.distanceMap[i] = 0;
+}
+
+// Running-mean start distance (R.cpp:254-266, encodeNodeEstimate R.cpp:415-455).
+// The filter state (S,C) feeds back into every decision, so the level is walked in
+// order by ONE wave per brick: 64 nodes per step, each lane deciding from the exact
+// integer closed form
+//     counted <=> pd>0 && ( S < pd*(2C+1) || (t>p && 2t-p>255) || (t<p && 2t<p) )
+// with (S,C) = carried state + prefix over the lower lanes' decisions; the ballot is
+// iterated to its fixed point, which equals the serial result by induction on lanes.
+__global__ void __launch_bounds__(64)
+k_estimate(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
+           int64_t leafStride)
+{
+    const int brick = blockIdx.x;
+    Ctrl &c = ctrls[brick];
+    const int lane = threadIdx.x;
+    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
+    const uint32_t n = 1u << d;
+    unsigned long long S = 0;
+    uint32_t C = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t i = base + lane;
+        bool valid = i < n;
+        int t = valid ? T[i] : 0;
+        int p = (valid && d > 0) ? P[i >> 1] : 0;
+        int pd = p > t ? p - t : t - p;
+        bool forced = (t > p && 2 * t - p > 255) || (t < p && 2 * t < p);
+        bool cand = valid && pd > 0;
+        bool dec = cand;
+        unsigned long long mask;
+        uint32_t spre = 0;
+        for (int it = 0; it < 65; ++it) {
+            mask = __ballot(dec);
+            uint32_t cpre = __popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t v = dec ? (uint32_t)pd : 0u;
+            uint32_t incl = v;
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t u = __shfl_up(incl, o);
+                if (lane >= o) incl += u;
+            }
+            spre = incl - v;
+            unsigned long long Si = S + spre;
+            unsigned long long rhs = (unsigned long long)pd * (2ull * (C + cpre) + 1ull);
+            bool nd = cand && (forced || Si < rhs);
+            unsigned long long nmask = __ballot(nd);
+            dec = nd;
+            if (nmask == mask) break;
+        }
+        uint32_t v = dec ? (uint32_t)pd : 0u;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        S += v;
+        C += __popcll(mask);
+    }
+    if (lane == 0) {
+        c.currentDistance = C > 0 ? round((double)S / (double)C) : 0.0; // R.cpp:263-266
+        c.previousDistance = 0.0;  // R.cpp:272-274
+        c.previousStepSize = 255.0;
+        c.previousError = 65025.0;
+        c.epoch = 0;
+        c.active = maxEpochs > 0 ? 1 : 0;
+        c.fillThisEpoch = c.active;
+        c.errMinus = c.errPlus = 0;
+        c.cur = 0; c.prev = 1; c.pendingEqual = 0;
+    }
+}
+
+__device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    unsigned long long r = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r; // valid in thread 0
+}
+
+// One gradient-descent evaluation of a level (R.cpp:307-313 fused with :336-359):
+// writes the 2-bit code and the reconstruction at `current`, and accumulates err^2 at
+// current (per-block partials, summed in node order by k_control to reproduce the
+// reference's serial double sum) and at current-1 / current+1 (exact integer atomics).
+__global__ void __launch_bounds__(256)
+k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
+       ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+{
+    __shared__ unsigned long long sh[4];
+    const int brick = blockIdx.y;
+    Ctrl &c = ctrls[brick];
+    if (!c.fillThisEpoch) return;
+    const uint32_t n = 1u << d;
+    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    uint8_t *Cd = codes + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
+    uint8_t *R = rb.b[phys_buf(c, c.cur)] + (int64_t)brick * leafStride;
+    const int dist = (int)(uint8_t)c.currentDistance;
+    const int distM = (int)(uint8_t)fmax(0.0, c.currentDistance - 1.0);   // R.cpp:334
+    const int distP = (int)(uint8_t)fmin(255.0, c.currentDistance + 1.0);
+    unsigned long long e0 = 0, em = 0, ep = 0;
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t i = i0 + k;
+        if (i < n) {
+            int t = T[i];
+            int p = d > 0 ? P[i >> 1] : 0;
+            Enc e = encode_node(t, p, dist);
+            Cd[i] = (uint8_t)e.code;
+            R[i] = (uint8_t)e.recon;
+            e0 += (unsigned)(e.err * e.err);
+            int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
+            em += (unsigned)(a * a);
+            ep += (unsigned)(b * b);
+        }
+    }
+    e0 = block_sum_u64(e0, sh);
+    em = block_sum_u64(em, sh);
+    ep = block_sum_u64(ep, sh);
+    if (threadIdx.x == 0) {
+        blockErr[(int64_t)brick * nErrBlk + blockIdx.x] = e0;
+        if (em) atomicAdd(&c.errMinus, em);
+        if (ep) atomicAdd(&c.errPlus, ep);
+    }
+}
+
+// End of epoch e and head of epoch e+1 of the while loop at R.cpp:275-366, one thread
+// per brick.  `currentError += err^2` runs over the level in node order starting from
+// a fractional carry (defect C-1), so the double rounds only when the running sum
+// crosses a power of two: block partials are added whole while the sum provably stays
+// inside its binade (every partial sum is then exactly representable) and node by
+// node inside the block where it crosses.
+__global__ void k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restrict__ temp,
+                          int64_t heapStride, ReconBufs rb, int64_t leafStride,
+                          const unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+{
+    if (threadIdx.x) return;
+    const int brick = blockIdx.x;
+    Ctrl &c = ctrls[brick];
+    const uint32_t n = 1u << d;
+    if (c.active && c.fillThisEpoch) {
+        const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
+        const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
+        const int dist = (int)(uint8_t)c.currentDistance;
+        const uint32_t nblk = (n + FILL_NODES_PER_BLOCK - 1) / FILL_NODES_PER_BLOCK;
+        double s = c.currentError;
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            unsigned long long e2 = blockErr[(int64_t)brick * nErrBlk + blk];
+            if (e2 == 0) continue;
+            bool whole = false;
+            double cand = s + (double)e2;
+            if (s == 0.0) whole = true;            // integers below 2^53: exact
+            else {
+                int ex;
+                frexp(s, &ex);                     // s in [2^(ex-1), 2^ex)
+                whole = cand < ldexp(1.0, ex);     // stays in the binade -> exact
+            }
+            if (whole) { s = cand; continue; }
+            uint32_t lo = blk * FILL_NODES_PER_BLOCK, hi = lo + FILL_NODES_PER_BLOCK;
+            if (hi > n) hi = n;
+            for (uint32_t i = lo; i < hi; ++i) {
+                int t = T[i];
+                int p = d > 0 ? P[i >> 1] : 0;
+                int er = encode_node(t, p, dist).err;
+                s += (double)(er * er);
+            }
+        }
+        c.currentError = s / (double)n;                        // R.cpp:315
+        if (c.currentError < 1.0) {                            // R.cpp:319
+            c.active = 0;
+        } else if (c.epoch != 0 && c.currentError > c.previousError) { // revert R.cpp:323-331
+            c.currentError = c.previousError;
+            c.currentDistance = c.previousDistance;
+            c.currentDF = c.previousDF;
+            c.currentStepSize = c.previousStepSize / 2.0;
+            int tmp = c.cur; c.cur = c.prev; c.prev = tmp;     // recon.swap(reconPreviousEpoch)
+            c.pendingEqual = 0;
+            c.numReverts++;
+            c.epoch++;
+        } else {
+            if (!guarded || c.epoch + 1 < maxEpochs) {         // VolumeKdtree.cpp:333 guard
+                double e0 = (double)c.errMinus / (double)n;    // R.cpp:346,357
+                double e1 = (double)c.errPlus / (double)n;
+                c.currentDF = (e1 - e0) / 2.0;                 // R.cpp:361, h = 1
+                c.currentStepSize = fmax(-4.0, fmin(4.0, -1.25 * c.currentDF));
+                // reconPreviousEpoch = recon (R.cpp:364) without a copy: the buffer just
+                // written becomes the snapshot and the next fill goes to the other one.
+                c.prev = c.cur;
+                c.cur = 1 - c.cur;
+                c.pendingEqual = 1;
+            }
+            c.epoch++;
+        }
+    }
+    if (c.active) {                                            // while-condition + loop head
+        if (!(c.epoch < maxEpochs && fabs(c.previousStepSize) >= 0.5)) {
+            c.active = 0;
+        } else if (c.epoch != 0) {
+            c.previousDistance = c.currentDistance;
+            c.previousError = c.currentError;
+            c.previousDF = c.currentDF;
+            c.previousStepSize = c.currentStepSize;
+            c.currentDistance = round(fmin(255.0, fmax(0.0, c.previousDistance + c.previousStepSize)));
+            if (c.currentDistance == c.previousDistance) c.active = 0; // R.cpp:287-288
+        }
+    }
+    c.fillThisEpoch = c.active;
+    c.errMinus = c.errPlus = 0;
+    if (c.active) c.pendingEqual = 0; // the coming fill overwrites the non-snapshot buffer
+}
+
+// R.cpp:369-381: record the level's distance, make its reconstruction the next level's parents.
+__global__ void k_level_end(int d, Ctrl *ctrls)
+{
+    if (threadIdx.x) return;
+    Ctrl &c = ctrls[blockIdx.x];
+    c.distanceMap[d] = (uint8_t)c.currentDistance;
+    int finalRole = c.pendingEqual ? c.prev : c.cur;
+    int finalPhys = phys_buf(c, finalRole);
+    int otherPhys = phys_buf(c, 1 - finalRole);
+    int oldPar = c.par;
+    c.par = finalPhys;
+    c.ra = oldPar;
+    c.rb = otherPhys;
+    c.cur = 0; c.prev = 1; c.pendingEqual = 0;
+    c.active = 0; c.fillThisEpoch = 0;
+}
+
+// The range stream's prune follows the mid stream (M.cpp:864-865); see k_prune_*.
+// ------------------------------------------------------------------ prune ----
+__global__ void __launch_bounds__(256)
+k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
+             uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride)
+{
+    const int brick = blockIdx.y;
+    Ctrl &c = ctrls[brick];
+    const uint32_t n = 1u << D;
+    uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    int err = 0;
+    if (r < n) {
+        const int64_t hi = (int64_t)brick * heapStride + ((int64_t)1 << D) + r;
+        int t = temp[hi];
+        int rec = rb.b[c.par][(int64_t)brick * leafStride + r];
+        err = rec > t ? rec - t : t - rec;
+        if (codes[hi] == 0 && err < tol) {   // R.cpp:618-626 (leaf: no children)
+            codes[hi] = 3;
+            if (codesRange) codesRange[hi] = 3;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(err, o); err = u > err ? u : err; }
+    if ((threadIdx.x & 63) == 0 && err > 0) atomicMax(&c.maxErrBefore, err); // R.cpp:71-76
+}
+
+__global__ void __launch_bounds__(256)
+k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRange, int64_t heapStride)
+{
+    const int brick = blockIdx.y;
+    const uint32_t n = 1u << d;
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    uint8_t *Cb = codes + (int64_t)brick * heapStride;
+    const int64_t me = ((int64_t)1 << d) + p, ch = ((int64_t)1 << (d + 1)) + 2 * (int64_t)p;
+    if (Cb[ch] == 3 && Cb[ch + 1] == 3 && Cb[me] == 0) {  // R.cpp:624
+        Cb[me] = 3;
+        if (codesRange) codesRange[(int64_t)brick * heapStride + me] = 3;
+    }
+}
+
+// ---------------------------------------------------------------- convert ----
+// Tokens owned by leaf rank r, in stream order: the live internal nodes whose first
+// leaf is r (depth ascending), then the leaf token and its grown chain (R.cpp:655-704).
+// A node is live iff it is the root or its parent was not pruned (pruning is closed
+// downwards, so "some ancestor pruned" == "parent pruned").
+struct Owned {
+    unsigned long long spineBits; // 2 bits per token, first token in the low bits
+    uint32_t leafBits;
+    unsigned long long spineBitsR; // MidRangeTree: the range stream's codes for the same tokens
+    uint32_t leafBitsR;
+    int nSpine, nLeaf;
+    int preDs;       // tokens owned by r that precede the depth-Ds node (index entry)
+    int aliveAtDs;
+    int finalErr;    // |recon - temp| of the leaf after branch growth (-1: leaf not visited)
+};
+
+__device__ inline Owned owned_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ CbR,
+                                     const uint8_t *__restrict__ Tb, const uint8_t *__restrict__ TbR,
+                                     const uint8_t *__restrict__ Rl, const uint8_t *__restrict__ RlR, int D,
+                                     int maxDepth, int tol, const uint8_t *dmap, const uint8_t *dmapR, int Ds,
+                                     uint32_t r)
+{
+    Owned o;
+    o.spineBits = 0; o.leafBits = 0; o.spineBitsR = 0; o.leafBitsR = 0;
+    o.nSpine = 0; o.nLeaf = 0; o.preDs = 0; o.aliveAtDs = 0; o.finalErr = -1;
+    const int jmin = r ? D - (__ffs((int)r) - 1) : 0;
+    bool alive = true;
+    if (jmin > 0) alive = Cb[((int64_t)1 << (jmin - 1)) + (r >> (D - jmin + 1))] != 3;
+    int j = jmin;
+    for (; alive && j < D; ++j) {
+        if (j == Ds) { o.preDs = o.nSpine; o.aliveAtDs = 1; }
+        const int64_t ni = ((int64_t)1 << j) + (r >> (D - j));
+        int code = Cb[ni];
+        o.spineBits |= (unsigned long long)code << (2 * o.nSpine);
+        if (CbR) o.spineBitsR |= (unsigned long long)CbR[ni] << (2 * o.nSpine);
+        o.nSpine++;
+        if (code == 3) alive = false;
+    }
+    if (alive) {
+        if (Ds == D) { o.preDs = o.nSpine; o.aliveAtDs = 1; }
+        const int64_t li = ((int64_t)1 << D) + r;
+        int code = Cb[li];
+        o.leafBits = (uint32_t)code;
+        if (CbR) o.leafBitsR = CbR[li];
+        o.nLeaf = 1;
+        int t = Tb[li], rec = Rl[r];
+        int tR = 0, recR = 0;
+        if (CbR) { tR = TbR[li]; recR = RlR[r]; }
+        if (code != 3) {
+            int depth = D;
+            while (depth < maxDepth) {
+                int err = rec > t ? rec - t : t - rec;
+                if (err > tol) {                       // grow the branch (R.cpp:695-697, 657-660)
+                    depth++;
+                    Enc e = encode_node(t, rec, dmap[depth]);
+                    rec = e.recon;
+                    o.leafBits |= (uint32_t)e.code << (2 * o.nLeaf);
+                    if (CbR) {                         // M.cpp: range stream re-encoded in lock-step
+                        Enc er = encode_node(tR, recR, dmapR[depth]);
+                        recR = er.recon;
+                        o.leafBitsR |= (uint32_t)er.code << (2 * o.nLeaf);
+                    }
+                    o.nLeaf++;
+                } else {                               // terminator (R.cpp:699-703, 671-674)
+                    o.leafBits |= 3u << (2 * o.nLeaf);
+                    if (CbR) o.leafBitsR |= 3u << (2 * o.nLeaf);
+                    o.nLeaf++;
+                    break;
+                }
+            }
+        }
+        o.finalErr = rec > t ? rec - t : t - rec;
+    }
+    return o;
+}
+
+struct EmitArgs {
+    const uint8_t *codes, *codesR, *temp, *tempR;
+    ReconBufs rb, rbR;
+    Ctrl *ctrls, *ctrlsR;
+    int64_t heapStride, leafStride;
+    int D, maxDepth, tol, Ds, K;
+    uint32_t *blockTot, *blockOff;
+    int64_t nEmitBlk;
+    uint8_t *tree, *treeR;
+    int64_t treeCap;
+    uint32_t *idxOff;
+    uint8_t *idxVal;
+    int64_t nIdx;
+};
+
+__device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t *shWave, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) shWave[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { if (i < w) woff += shWave[i]; tot += shWave[i]; }
+    __syncthreads();
+    total = tot;
+    return woff + incl - v;
+}
+
+__global__ void __launch_bounds__(EMIT_RANKS_PER_BLOCK)
+k_emit_count(EmitArgs a)
+{
+    __shared__ uint32_t shw[4];
+    const int brick = blockIdx.y;
+    const Ctrl &c = a.ctrls[brick];
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
+    const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
+    const uint32_t n = 1u << a.D;
+    uint32_t r = blockIdx.x * EMIT_RANKS_PER_BLOCK + threadIdx.x;
+    uint32_t w = 0;
+    if (r < n) {
+        Owned o = owned_tokens(Cb, nullptr, Tb, nullptr, Rl, nullptr, a.D, a.maxDepth, a.tol, c.distanceMap, nullptr,
+                               a.Ds, r);
+        w = o.nSpine + o.nLeaf;
+    }
+    uint32_t tot;
+    block_excl_scan_u32(w, shw, tot);
+    if (threadIdx.x == 0) a.blockTot[(int64_t)brick * a.nEmitBlk + blockIdx.x] = tot;
+}
+
+// exclusive scan of the per-block token counts of one brick (one block per brick)
+__global__ void __launch_bounds__(1024)
+k_emit_scan(EmitArgs a, int64_t nblk)
+{
+    __shared__ uint32_t shw[16];
+    __shared__ uint32_t carrySh;
+    const int brick = blockIdx.x;
+    const uint32_t *in = a.blockTot + (int64_t)brick * a.nEmitBlk;
+    uint32_t *out = a.blockOff + (int64_t)brick * a.nEmitBlk;
+    if (threadIdx.x == 0) carrySh = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblk; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        uint32_t v = i < nblk ? in[i] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan_u32(v, shw, tot);
+        uint32_t carry = carrySh;
+        if (i < nblk) out[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carrySh = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.ctrls[brick].numActive = carrySh;     // numActiveNodes (R.cpp:714)
+        if (a.ctrlsR) a.ctrlsR[brick].numActive = carrySh;
+    }
+}
+
+// Words that contain a block boundary are merged with atomicOr; they are zeroed here
+// first (every shared word is the first or last word of some block's token range).
+__global__ void __launch_bounds__(256)
+k_emit_zero(EmitArgs a, int64_t nblk)
+{
+    const int brick = blockIdx.y;
+    int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nblk) return;
+    uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blk];
+    uint32_t tot = a.blockTot[(int64_t)brick * a.nEmitBlk + blk];
+    uint32_t *W = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
+    uint32_t *WR = a.treeR ? (uint32_t *)(a.treeR + (int64_t)brick * a.treeCap) : nullptr;
+    if (tot == 0) {
+        if (blk == 0 && a.ctrls[brick].numActive == 0) { W[0] = 0; if (WR) WR[0] = 0; }
+        return;
+    }
+    W[g0 >> 4] = 0;
+    W[(g0 + tot - 1) >> 4] = 0;
+    if (WR) { WR[g0 >> 4] = 0; WR[(g0 + tot - 1) >> 4] = 0; }
+}
+
+#define EMIT_LDS_WORDS 256   // 4096 tokens >= 256*9 + 511 + 32 (+15 phase)
+
+__device__ inline void lds_put(uint32_t *W, uint32_t pos, uint32_t bits, int ntok)
+{
+    if (ntok <= 0) return;
+    unsigned long long v = (unsigned long long)bits << ((pos & 15u) * 2u);
+    uint32_t w = pos >> 4;
+    atomicOr(&W[w], (uint32_t)v);
+    uint32_t hi = (uint32_t)(v >> 32);
+    if (hi) atomicOr(&W[w + 1], hi);
+}
+
+__global__ void __launch_bounds__(EMIT_RANKS_PER_BLOCK)
+k_emit_write(EmitArgs a)
+{
+    __shared__ uint32_t shw[4];
+    __shared__ uint32_t W[EMIT_LDS_WORDS], WR[EMIT_LDS_WORDS];
+    const int brick = blockIdx.y;
+    Ctrl &c = a.ctrls[brick];
+    const bool mr = a.codesR != nullptr;
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
+    const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
+    const uint8_t *CbR = mr ? a.codesR + (int64_t)brick * a.heapStride : nullptr;
+    const uint8_t *TbR = mr ? a.tempR + (int64_t)brick * a.heapStride : nullptr;
+    const uint8_t *RlR = mr ? a.rbR.b[a.ctrlsR[brick].par] + (int64_t)brick * a.leafStride : nullptr;
+    const uint8_t *dmapR = mr ? a.ctrlsR[brick].distanceMap : nullptr;
+    const uint32_t n = 1u << a.D;
+    const uint32_t r = blockIdx.x * EMIT_RANKS_PER_BLOCK + threadIdx.x;
+    for (int i = threadIdx.x; i < EMIT_LDS_WORDS; i += blockDim.x) { W[i] = 0; WR[i] = 0; }
+    Owned o;
+    o.nSpine = o.nLeaf = 0; o.finalErr = -1; o.aliveAtDs = 0; o.preDs = 0;
+    if (r < n) o = owned_tokens(Cb, CbR, Tb, TbR, Rl, RlR, a.D, a.maxDepth, a.tol, c.distanceMap, dmapR, a.Ds, r);
+    uint32_t w = o.nSpine + o.nLeaf, tot;
+    uint32_t lo = block_excl_scan_u32(w, shw, tot); // also orders the LDS clear above
+    const uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blockIdx.x];
+    const uint32_t phase = g0 & 15u;
+    if (w) {
+        uint32_t pos = phase + lo;
+        lds_put(W, pos, (uint32_t)o.spineBits, o.nSpine < 16 ? o.nSpine : 16);
+        if (o.nSpine > 16) lds_put(W, pos + 16, (uint32_t)(o.spineBits >> 32), o.nSpine - 16);
+        lds_put(W, pos + o.nSpine, o.leafBits, o.nLeaf);
+        if (mr) {
+            lds_put(WR, pos, (uint32_t)o.spineBitsR, o.nSpine < 16 ? o.nSpine : 16);
+            if (o.nSpine > 16) lds_put(WR, pos + 16, (uint32_t)(o.spineBitsR >> 32), o.nSpine - 16);
+            lds_put(WR, pos + o.nSpine, o.leafBitsR, o.nLeaf);
+        }
+    }
+    // decode side-car index: one entry per depth-Ds subtree root
+    if (r < n && (r & ((1u << a.K) - 1u)) == 0) {
+        const uint32_t s = r >> a.K;
+        int val = c.distanceMap[0];              // root scalar (R.cpp:743)
+        for (int j = 1; j <= a.Ds; ++j) {
+            int code = Cb[((int64_t)1 << j) + (s >> (a.Ds - j))];
+            val = apply_code(val, code, c.distanceMap[j]); // pruned descendants carry code 3: unchanged
+        }
+        a.idxOff[(int64_t)brick * a.nIdx + s] = o.aliveAtDs ? g0 + lo + (uint32_t)o.preDs : VR_IDX_DEAD;
+        a.idxVal[(int64_t)brick * a.nIdx + s] = (uint8_t)val;
+    }
+    // encoder's own statistics after branch growth (R.cpp:115-129)
+    int fe = o.finalErr > 0 ? o.finalErr : 0;
+    unsigned long long l1 = (unsigned long long)fe;
+    for (int q = 32; q > 0; q >>= 1) { int u = __shfl_xor(fe, q); fe = u > fe ? u : fe; l1 += __shfl_xor(l1, q); }
+    if ((threadIdx.x & 63) == 0) {
+        if (fe > 0) atomicMax(&c.maxErrAfter, fe);
+        if (l1) atomicAdd(&c.statL1, l1);
+    }
+    __syncthreads();
+    if (tot == 0) return;
+    uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
+    uint32_t *GR = mr ? (uint32_t *)(a.treeR + (int64_t)brick * a.treeCap) + (g0 >> 4) : nullptr;
+    const uint32_t nw = ((phase + tot - 1) >> 4) + 1;
+    for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
+        if (i == 0 || i == nw - 1) { if (W[i]) atomicOr(&G[i], W[i]); if (mr && WR[i]) atomicOr(&GR[i], WR[i]); }
+        else { G[i] = W[i]; if (mr) GR[i] = WR[i]; }
+    }
+}
+
+// ------------------------------------------------------------ host driver ----
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
+{
+    const int D = bs->D, B = bs->B;
+    ReconBufs rb{{s.recon[0], s.recon[1], s.recon[2]}};
+    const int guarded = bs->variant != 0; // GUARDED and MIDRANGE both carry the :333/:340 guard
+    hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl);
+    if (bs->maxEpochs <= 0) // recon.resize() zero-fill is the level result when the loop never runs
+        for (int i = 0; i < 3; ++i) hipMemsetAsync(s.recon[i], 0, (size_t)B * bs->leafStride, st);
+    for (int d = 0; d <= D; ++d) {
+        const int64_t n = (int64_t)1 << d;
+        hipLaunchKernelGGL(k_estimate, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride, rb,
+                           bs->leafStride);
+        for (int e = 0; e < bs->maxEpochs; ++e) {
+            hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
+                               s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+            hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, guarded, s.ctrl, s.temp,
+                               bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+        }
+        hipLaunchKernelGGL(k_level_end, dim3(B), dim3(64), 0, st, d, s.ctrl);
+    }
+}
+
+__global__ void k_fix_chain_distances(int D, int maxDepth, Ctrl *ctrls, Ctrl *ctrlsR)
+{
+    if (threadIdx.x) return;
+    const int add[VR_CHAIN_LEVELS] = {64, 32, 16, 8, 4, 2, 1}; // R.cpp:23,94-97
+    for (int dd = D + 1, i = 0; dd <= maxDepth; ++dd, ++i) {
+        ctrls[blockIdx.x].distanceMap[dd] = (uint8_t)add[i];
+        if (ctrlsR) ctrlsR[blockIdx.x].distanceMap[dd] = (uint8_t)add[i];
+    }
+}
+
+int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
+{
+    const int D = bs->D, B = bs->B;
+    const bool mr = bs->variant == 2;
+    hipEventRecord(bs->ev[0], st);
+    // ---- BUILD: pyramid in rounds of <= 10 levels
+    {
+        int dLeaf = D, round = 0;
+        const uint8_t *inMin = nullptr, *inMax = nullptr;
+        int64_t inStride = 0;
+        while (true) {
+            int L = dLeaf < 10 ? dLeaf : 10;
+            int64_t nblk = (int64_t)1 << (dLeaf - L);
+            uint8_t *oMin = bs->mmMin[round & 1], *oMax = bs->mmMax[round & 1];
+            int64_t oStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
+            if (round == 0)
+                hipLaunchKernelGGL(k_pyramid<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, bs->g, dLeaf, L, vox,
+                                   inMin, inMax, inStride, bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr,
+                                   oMin, oMax, oStride);
+            else
+                hipLaunchKernelGGL(k_pyramid<false>, dim3((unsigned)nblk, B), dim3(256), 0, st, bs->g, dLeaf, L, vox,
+                                   inMin, inMax, inStride, bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr,
+                                   oMin, oMax, oStride);
+            dLeaf -= L;
+            if (dLeaf == 0) break;
+            inMin = oMin; inMax = oMax; inStride = oStride;
+            ++round;
+        }
+    }
+    hipEventRecord(bs->ev[1], st);
+    // ---- COMPRESS
+    compress_stream(bs, bs->mid, st);
+    if (mr) compress_stream(bs, bs->rng, st);
+    hipEventRecord(bs->ev[2], st);
+    // ---- PRUNE
+    ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
+    ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
+    hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
+                       bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
+                       bs->leafStride);
+    for (int d = D - 1; d >= 0; --d)
+        hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.codes,
+                           mr ? bs->rng.codes : nullptr, bs->heapStride);
+    hipLaunchKernelGGL(k_fix_chain_distances, dim3(B), dim3(64), 0, st, D, bs->maxDepth, bs->mid.ctrl,
+                       mr ? bs->rng.ctrl : nullptr);
+    hipEventRecord(bs->ev[3], st);
+    // ---- CONVERT
+    EmitArgs a;
+    a.codes = bs->mid.codes; a.codesR = mr ? bs->rng.codes : nullptr;
+    a.temp = bs->mid.temp; a.tempR = mr ? bs->rng.temp : nullptr;
+    a.rb = rb; a.rbR = rbR;
+    a.ctrls = bs->mid.ctrl; a.ctrlsR = mr ? bs->rng.ctrl : nullptr;
+    a.heapStride = bs->heapStride; a.leafStride = bs->leafStride;
+    a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
+    a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
+    a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
+    a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
+    const int64_t nblk = cdiv((int64_t)1 << D, EMIT_RANKS_PER_BLOCK);
+    hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
+    hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
+    hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
+    hipEventRecord(bs->ev[4], st);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+} // namespace vr

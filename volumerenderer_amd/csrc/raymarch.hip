@@ -1,0 +1,317 @@
+// raymarch.hip -- gfx950 kernels for the front-to-back ray-marching compositor
+// (reference volume_renderer/raycaster.frag:18-86), the iso-surface marcher
+// (volume_renderer/isosurface.frag:23-159), the vertex stage / proxy cube they run on
+// (raycaster.vert:10-21, UnitBrick.h:54-100, main.cpp:396-402), plus the small
+// data-parallel helpers of the path: brick assembly (VolumeReader.h:151-223), error
+// metrics (VolumeKdTree_recover.cpp:386-411) and sort-last compositing.
+//
+// One thread per pixel; a 64-lane wave covers an 8x8 pixel tile so neighbouring rays
+// touch neighbouring voxels (L1/L2 locality of the 8 trilinear taps).  The cube
+// rasteriser is replaced by its per-pixel equivalent: nearest cube-surface point along
+// the view ray inside [near, far] (GL_LESS, no culling: main.cpp:367-369).
+#include "../../include/vrhip.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace vr {
+
+struct Tex {
+    const uint8_t *v;
+    int X, Y, Z;       // local extents
+    int GX, GY, GZ;    // global extents (== local on the single-GPU path)
+    int ox, oy, oz;    // global index of local voxel 0
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// texture(volume, p).r : R8 normalised, GL_LINEAR, clamp-to-edge, float32 weights
+__device__ __forceinline__ float tex3d(const Tex &t, float px, float py, float pz)
+{
+    float x = px * (float)t.GX - 0.5f, y = py * (float)t.GY - 0.5f, z = pz * (float)t.GZ - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y), fz0 = floorf(z);
+    float fx = x - fx0, fy = y - fy0, fz = z - fz0;
+    int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+    int xa = clampi(clampi(x0, 0, t.GX - 1) - t.ox, 0, t.X - 1), xb = clampi(clampi(x0 + 1, 0, t.GX - 1) - t.ox, 0, t.X - 1);
+    int ya = clampi(clampi(y0, 0, t.GY - 1) - t.oy, 0, t.Y - 1), yb = clampi(clampi(y0 + 1, 0, t.GY - 1) - t.oy, 0, t.Y - 1);
+    int za = clampi(clampi(z0, 0, t.GZ - 1) - t.oz, 0, t.Z - 1), zb = clampi(clampi(z0 + 1, 0, t.GZ - 1) - t.oz, 0, t.Z - 1);
+    const float k = 1.0f / 255.0f;
+    const int64_t sy = t.X, sz = (int64_t)t.X * t.Y;
+    const uint8_t *r0 = t.v + sy * ya + sz * za, *r1 = t.v + sy * yb + sz * za;
+    const uint8_t *r2 = t.v + sy * ya + sz * zb, *r3 = t.v + sy * yb + sz * zb;
+    float c000 = (float)r0[xa] * k, c100 = (float)r0[xb] * k, c010 = (float)r1[xa] * k, c110 = (float)r1[xb] * k;
+    float c001 = (float)r2[xa] * k, c101 = (float)r2[xb] * k, c011 = (float)r3[xa] * k, c111 = (float)r3[xb] * k;
+    float c00 = c000 + fx * (c100 - c000), c10 = c010 + fx * (c110 - c010);
+    float c01 = c001 + fx * (c101 - c001), c11 = c011 + fx * (c111 - c011);
+    float c0 = c00 + fy * (c10 - c00), c1 = c01 + fy * (c11 - c01);
+    return c0 + fz * (c1 - c0);
+}
+
+__device__ __forceinline__ void norm3(float &a, float &b, float &c)
+{
+    float l = sqrtf(a * a + b * b + c * c);
+    if (l > 0.0f) { a /= l; b /= l; c /= l; } else { a = b = c = 0.0f; }
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ bool inside(float x, float y, float z)
+{   // stop = dot(sign(p - texMin), sign(texMax - p)) < 3.0  (raycaster.frag:51)
+    float d = sgn(x) * sgn(1.0f - x) + sgn(y) * sgn(1.0f - y) + sgn(z) * sgn(1.0f - z);
+    return !(d < 3.0f);
+}
+
+struct RayArgs {
+    Tex t;
+    vr_camera cam;
+    vr_render_params P;
+    float f[3], s[3], u[3];
+    float tanX, tanY;
+    float *out;
+};
+
+__global__ void __launch_bounds__(64)
+k_raycast(RayArgs a)
+{
+    // 8x8 pixel tile per wave
+    const int px = blockIdx.x * 8 + (threadIdx.x & 7), py = blockIdx.y * 8 + (threadIdx.x >> 3);
+    const int W = a.P.width, H = a.P.height;
+    if (px >= W || py >= H) return;
+    float *o = a.out + 4 * ((size_t)py * W + px);
+    const float nx = 2.0f * ((float)px + 0.5f) / (float)W - 1.0f;
+    const float ny = 1.0f - 2.0f * ((float)py + 0.5f) / (float)H;
+    float dir[3], cp[3] = {a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dir[k] = a.f[k] + nx * a.tanX * a.s[k] + ny * a.tanY * a.u[k];
+    float t0 = -INFINITY, t1 = INFINITY;
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (dir[k] != 0.0f) {
+            float lo = (-0.5f - cp[k]) / dir[k], hi = (0.5f - cp[k]) / dir[k];
+            if (lo > hi) { float q = lo; lo = hi; hi = q; }
+            if (lo > t0) t0 = lo;
+            if (hi < t1) t1 = hi;
+        } else if (cp[k] < -0.5f || cp[k] > 0.5f) miss = true;
+    }
+    const float th = t0 >= a.cam.z_near ? t0 : t1;
+    const int mode = a.P.mode;
+    if (miss || t0 > t1 || th < a.cam.z_near || th > a.cam.z_far) {
+        if (mode == VR_RENDER_PARTIAL) { o[0] = 0.0f; o[1] = 1.0f; o[2] = 0.0f; o[3] = 0.0f; }
+        else { o[0] = o[1] = o[2] = o[3] = 1.0f; }   // clear colour (main.cpp:392)
+        return;
+    }
+    float vuv[3], gd[3], st[3], pos[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vuv[k] = (cp[k] + th * dir[k]) + 0.5f;      // vUV = vVertex + 0.5
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gd[k] = (vuv[k] - 0.5f) - cp[k];            // raycaster.frag:27
+    norm3(gd[0], gd[1], gd[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { st[k] = gd[k] * a.P.step_size[k]; pos[k] = vuv[k]; }
+    const int ns = a.P.max_samples;
+    if (mode == VR_RENDER_COMPOSITE) {
+        float rgb = 0.0f, A = 0.0f;
+        for (int i = 0; i < ns; ++i) {
+            pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
+            if (!inside(pos[0], pos[1], pos[2])) break;
+            float smp = tex3d(a.t, pos[0], pos[1], pos[2]);
+            float pa = smp - (smp * A);          // raycaster.frag:69
+            rgb = pa * smp + rgb;                // :70
+            A += pa * 0.6f;                      // :72
+            if (!a.P.no_early_exit && A > 0.99f) break; // :77
+        }
+        o[0] = 1.0f - rgb; o[1] = 1.0f - rgb; o[2] = 1.0f; o[3] = A;   // :82-85 (b = 255 clamps)
+    } else if (mode == VR_RENDER_PARTIAL) {
+        float c = 0.0f, tau = 1.0f;
+        for (int i = 0; i < ns; ++i) {
+            pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
+            if (!inside(pos[0], pos[1], pos[2])) break;
+            bool own = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) own = own && (pos[k] >= a.P.box_min[k] && pos[k] < a.P.box_max[k]);
+            if (!own) continue;
+            float smp = tex3d(a.t, pos[0], pos[1], pos[2]);
+            c = c + tau * (smp * smp);
+            tau = tau * (1.0f - 0.6f * smp);
+        }
+        o[0] = c; o[1] = tau; o[2] = 1.0f; o[3] = 0.0f;
+    } else {
+        float col[4] = {1.0f, 1.0f, 1.0f, 1.0f};         // vec4(255,255,255,1) clamped (isosurface.frag:79)
+        const float iso = a.P.iso_value;
+        for (int i = 0; i < ns; ++i) {
+            pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
+            if (!inside(pos[0], pos[1], pos[2])) break;
+            float s1 = tex3d(a.t, pos[0], pos[1], pos[2]);
+            float s2 = tex3d(a.t, pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]);
+            if ((s1 - iso) < 0.0f && (s2 - iso) >= 0.0f) {                     // :126
+                float l[3] = {pos[0], pos[1], pos[2]}, r[3] = {pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]};
+                for (int b = 0; b < 4; ++b) {                                  // Bisection :23-42
+                    float m0 = (r[0] + l[0]) * 0.5f, m1 = (r[1] + l[1]) * 0.5f, m2 = (r[2] + l[2]) * 0.5f;
+                    float cm = tex3d(a.t, m0, m1, m2);
+                    if (cm < iso) { l[0] = m0; l[1] = m1; l[2] = m2; } else { r[0] = m0; r[1] = m1; r[2] = m2; }
+                }
+                float tc0 = (r[0] + l[0]) * 0.5f, tc1 = (r[1] + l[1]) * 0.5f, tc2 = (r[2] + l[2]) * 0.5f;
+                const float DELTA = 0.01f;                                     // GetGradient :47-62
+                float N0 = (tex3d(a.t, tc0 - DELTA, tc1, tc2) - tex3d(a.t, tc0 + DELTA, tc1, tc2)) / 2.0f;
+                float N1 = (tex3d(a.t, tc0, tc1 - DELTA, tc2) - tex3d(a.t, tc0, tc1 + DELTA, tc2)) / 2.0f;
+                float N2 = (tex3d(a.t, tc0, tc1, tc2 - DELTA) - tex3d(a.t, tc0, tc1, tc2 + DELTA)) / 2.0f;
+                norm3(N0, N1, N2);
+                float V0 = -gd[0], V1 = -gd[1], V2 = -gd[2];                   // head light: L = V (:142-146)
+                float diffuse = fmaxf(V0 * N0 + V1 * N1 + V2 * N2, 0.0f);
+                float h0 = V0 + V0, h1 = V1 + V1, h2 = V2 + V2;
+                norm3(h0, h1, h2);
+                float spec = powf(fmaxf(0.00001f, h0 * N0 + h1 * N1 + h2 * N2), 250.0f); // :73
+                col[0] = fminf(1.0f, diffuse * 0.39f + spec);
+                col[1] = fminf(1.0f, diffuse * 0.58f + spec);
+                col[2] = fminf(1.0f, diffuse * 0.93f + spec);
+                col[3] = 1.0f;
+                break;
+            }
+        }
+        o[0] = col[0]; o[1] = col[1]; o[2] = col[2]; o[3] = col[3];
+    }
+}
+
+__global__ void k_composite_over(float4 *front, const float4 *back, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 f = front[i], b = back[i];
+    f.x = f.x + f.y * b.x;       // (c1 + t1*c2, t1*t2)
+    f.y = f.y * b.y;
+    f.z = fmaxf(f.z, b.z);
+    front[i] = f;
+}
+
+__global__ void k_composite_finish(const float4 *partial, float4 *rgba, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = partial[i], o;
+    if (p.z > 0.0f) { o.x = 1.0f - p.x; o.y = 1.0f - p.x; o.z = 1.0f; o.w = 1.0f - p.y; }
+    else { o.x = o.y = o.z = o.w = 1.0f; }
+    rgba[i] = o;
+}
+
+// Brick <-> global volume placement (VolumeReader.h:172-211), 16-byte rows segments.
+template <bool TO_VOLUME>
+__global__ void __launch_bounds__(256)
+k_assemble(const uint8_t *src, uint8_t *dst, int nbricks, int64_t X, int64_t Y, int64_t Z, const int64_t *ijk,
+           int64_t I, int64_t J)
+{
+    const int b = blockIdx.y;
+    const int64_t xv = X / 16;                     // 16-byte vectors per row
+    const int64_t total = xv * Y * Z;
+    const int64_t i = ijk[3 * b], j = ijk[3 * b + 1], k = ijk[3 * b + 2];
+    const int64_t GX = X * I, GY = Y * J;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        int64_t xq = q % xv, y = (q / xv) % Y, z = q / (xv * Y);
+        int64_t bo = (int64_t)b * X * Y * Z + xq * 16 + X * (y + Y * z);
+        int64_t go = (i * X + xq * 16) + GX * ((j * Y + y) + GY * (k * Z + z));
+        if (TO_VOLUME) *(uint4 *)(dst + go) = *(const uint4 *)(src + bo);
+        else *(uint4 *)(dst + bo) = *(const uint4 *)(src + go);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_measure_error(const uint8_t *a, const uint8_t *b, int64_t n, int *maxErr, unsigned long long *sumErr)
+{
+    int m = 0;
+    unsigned long long s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int e = (int)a[i] - (int)b[i];
+        e = e < 0 ? -e : e;
+        m = e > m ? e : m;
+        s += (unsigned)e;
+    }
+    for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(m, o); m = u > m ? u : m; s += __shfl_xor(s, o); }
+    if ((threadIdx.x & 63) == 0) { if (m) atomicMax(maxErr, m); if (s) atomicAdd(sumErr, s); }
+}
+
+__global__ void __launch_bounds__(256)
+k_query_error(const uint8_t *a, const uint8_t *b, int64_t n, uint8_t *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int e = (int)a[i] - (int)b[i];
+        out[i] = (uint8_t)(e < 0 ? -e : e);
+    }
+}
+
+static void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void hnorm3(float *v)
+{
+    float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (l > 0.0f) { v[0] /= l; v[1] /= l; v[2] /= l; } else { v[0] = v[1] = v[2] = 0.0f; }
+}
+
+int raycast_launch(const uint8_t *vol, const int64_t dims[3], const vr_camera *cam, const vr_render_params *P,
+                   float *rgba, hipStream_t st)
+{
+    RayArgs a;
+    a.t.v = vol;
+    a.t.X = (int)dims[0]; a.t.Y = (int)dims[1]; a.t.Z = (int)dims[2];
+    a.t.GX = P->global_dims[0] > 0 ? (int)P->global_dims[0] : a.t.X;
+    a.t.GY = P->global_dims[1] > 0 ? (int)P->global_dims[1] : a.t.Y;
+    a.t.GZ = P->global_dims[2] > 0 ? (int)P->global_dims[2] : a.t.Z;
+    a.t.ox = (int)P->vol_origin[0]; a.t.oy = (int)P->vol_origin[1]; a.t.oz = (int)P->vol_origin[2];
+    a.cam = *cam;
+    a.P = *P;
+    // glm::lookAt basis and glm::perspectiveFov half-angle tangents (main.cpp:396-397)
+    for (int k = 0; k < 3; ++k) a.f[k] = cam->front[k];
+    hnorm3(a.f);
+    cross3(a.f, cam->up, a.s);
+    hnorm3(a.s);
+    cross3(a.s, a.f, a.u);
+    const float rad = cam->fov_deg * 0.01745329251994329576923690768489f;
+    a.tanY = tanf(0.5f * rad);
+    a.tanX = a.tanY * (float)P->width / (float)P->height;
+    a.out = rgba;
+    dim3 grid((P->width + 7) / 8, (P->height + 7) / 8);
+    hipLaunchKernelGGL(k_raycast, grid, dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int composite_over_launch(float *front, const float *back, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_composite_over, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4 *)front,
+                       (const float4 *)back, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int composite_finish_launch(const float *partial, float *rgba, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_composite_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const float4 *)partial, (float4 *)rgba, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int assemble_launch(bool toVolume, const uint8_t *src, uint8_t *dst, int nb, const int64_t bd[3], const int64_t *ijkDev,
+                    const int64_t grid[3], hipStream_t st)
+{
+    int64_t total = bd[0] / 16 * bd[1] * bd[2];
+    unsigned gx = (unsigned)((total + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    if (toVolume)
+        hipLaunchKernelGGL(k_assemble<true>, dim3(gx, nb), dim3(256), 0, st, src, dst, nb, bd[0], bd[1], bd[2], ijkDev,
+                           grid[0], grid[1]);
+    else
+        hipLaunchKernelGGL(k_assemble<false>, dim3(gx, nb), dim3(256), 0, st, src, dst, nb, bd[0], bd[1], bd[2], ijkDev,
+                           grid[0], grid[1]);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int measure_error_launch(const uint8_t *a, const uint8_t *b, int64_t n, int *maxErrDev, unsigned long long *sumDev,
+                         hipStream_t st)
+{
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_measure_error, dim3(g), dim3(256), 0, st, a, b, n, maxErrDev, sumDev);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int query_error_launch(const uint8_t *a, const uint8_t *b, int64_t n, uint8_t *out, hipStream_t st)
+{
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_query_error, dim3(g), dim3(256), 0, st, a, b, n, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+} // namespace vr
