@@ -631,8 +631,10 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
     ReconBufs rb{{s.recon[0], s.recon[1], s.recon[2]}};
     const int guarded = bs->variant != 0; // GUARDED and MIDRANGE both carry the :333/:340 guard
     hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl);
-    if (bs->maxEpochs <= 0) // recon.resize() zero-fill is the level result when the loop never runs
+    if (bs->maxEpochs <= 0) { // the loop never runs: tree.resize() / recon.resize() zero-fill is the result
         for (int i = 0; i < 3; ++i) hipMemsetAsync(s.recon[i], 0, (size_t)B * bs->leafStride, st);
+        hipMemsetAsync(s.codes, 0, (size_t)B * bs->heapStride, st);
+    }
     for (int d = 0; d <= D; ++d) {
         const int64_t n = (int64_t)1 << d;
         hipLaunchKernelGGL(k_estimate, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride, rb,
