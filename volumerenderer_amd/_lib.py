@@ -85,6 +85,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libvrhip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch ships its own libamdhip64; it must be in the process BEFORE libvrhip.so is
+        # loaded so that both bind to ONE HIP runtime (device pointers and streams are then
+        # interchangeable).  Loading libvrhip.so first would start a second runtime that cannot
+        # see the device torch holds.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported

@@ -5,6 +5,7 @@
 #include "brickset.h"
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
@@ -26,7 +27,10 @@ struct vr_brickset { BrickSet s; };
 static bool device_ok()
 {
     int n = 0;
-    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if ((e != hipSuccess || n <= 0) && getenv("VRHIP_DEBUG"))
+        fprintf(stderr, "[vrhip] hipGetDeviceCount: %s (n=%d)\n", hipGetErrorString(e), n);
+    return e == hipSuccess && n > 0;
 }
 
 extern "C" {

@@ -84,4 +84,8 @@ __host__ __device__ inline int apply_code(int v, int code, int dist)
     return v;
 }
 
+// launch check used by every host launcher: 0 on success; prints the HIP error when
+// VRHIP_DEBUG is set in the environment.
+int launch_status(const char *what);
+
 } // namespace vr

@@ -7,9 +7,19 @@
 // rebuilt from the bytes alone by build_index_from_stream) and the 2^Ds subtrees are
 // decoded independently.
 #include "brickset.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace vr {
+
+int launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    if (getenv("VRHIP_DEBUG")) fprintf(stderr, "[vrhip] %s: %s\n", what, hipGetErrorString(e));
+    return -1;
+}
 
 void make_geom(Geom &g, const int64_t dims[3])
 {
@@ -119,7 +129,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, hipStream_t st)
     hipEventRecord(bs->ev[5], st);
     hipLaunchKernelGGL(k_decode_lane, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
     hipEventRecord(bs->ev[6], st);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("decode");
 }
 
 // Serial pass over a foreign stream (host): the side-car index from the bytes alone.

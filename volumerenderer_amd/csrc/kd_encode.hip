@@ -722,7 +722,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
     hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     hipEventRecord(bs->ev[4], st);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("encode");
 }
 
 } // namespace vr

@@ -10,6 +10,7 @@
 // rasteriser is replaced by its per-pixel equivalent: nearest cube-surface point along
 // the view ray inside [near, far] (GL_LESS, no culling: main.cpp:367-369).
 #include "../../include/vrhip.h"
+#include "kd_common.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -269,20 +270,20 @@ int raycast_launch(const uint8_t *vol, const int64_t dims[3], const vr_camera *c
     a.out = rgba;
     dim3 grid((P->width + 7) / 8, (P->height + 7) / 8);
     hipLaunchKernelGGL(k_raycast, grid, dim3(64), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("raymarch");
 }
 
 int composite_over_launch(float *front, const float *back, int64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_composite_over, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float4 *)front,
                        (const float4 *)back, n);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("raymarch");
 }
 int composite_finish_launch(const float *partial, float *rgba, int64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_composite_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        (const float4 *)partial, (float4 *)rgba, n);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("raymarch");
 }
 int assemble_launch(bool toVolume, const uint8_t *src, uint8_t *dst, int nb, const int64_t bd[3], const int64_t *ijkDev,
                     const int64_t grid[3], hipStream_t st)
@@ -296,7 +297,7 @@ int assemble_launch(bool toVolume, const uint8_t *src, uint8_t *dst, int nb, con
     else
         hipLaunchKernelGGL(k_assemble<false>, dim3(gx, nb), dim3(256), 0, st, src, dst, nb, bd[0], bd[1], bd[2], ijkDev,
                            grid[0], grid[1]);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("raymarch");
 }
 int measure_error_launch(const uint8_t *a, const uint8_t *b, int64_t n, int *maxErrDev, unsigned long long *sumDev,
                          hipStream_t st)
@@ -304,14 +305,14 @@ int measure_error_launch(const uint8_t *a, const uint8_t *b, int64_t n, int *max
     unsigned g = (unsigned)((n + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_measure_error, dim3(g), dim3(256), 0, st, a, b, n, maxErrDev, sumDev);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("raymarch");
 }
 int query_error_launch(const uint8_t *a, const uint8_t *b, int64_t n, uint8_t *out, hipStream_t st)
 {
     unsigned g = (unsigned)((n + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_query_error, dim3(g), dim3(256), 0, st, a, b, n, out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("raymarch");
 }
 
 } // namespace vr
