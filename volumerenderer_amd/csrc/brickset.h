@@ -30,6 +30,9 @@ struct BrickSet {
     uint8_t *mmMin[2] = {nullptr, nullptr}, *mmMax[2] = {nullptr, nullptr}; // pyramid carry arrays
     unsigned long long *blockErr = nullptr; // B * nErrBlk : per-block sum err^2 of the fill pass
     int64_t nErrBlk = 0;
+    void *estSumm = nullptr;     // B * estSummStride EstSummary records (estimator, kd_encode.hip)
+    int64_t estSummStride = 0;
+    unsigned long long *blockL1 = nullptr; // B * nEmitBlk
     uint32_t *blockTot = nullptr, *blockOff = nullptr; // B * nEmitBlk
     int64_t nEmitBlk = 0;
     uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)

@@ -53,7 +53,10 @@ struct Ctrl {
     int32_t par, ra, rb;     // physical recon buffer indices: parents, level buffers
     int32_t numReverts;
     int32_t maxErrBefore, maxErrAfter;
-    int32_t pad;
+    int32_t estTbase;        // estimator: first candidate threshold of the current level
+    unsigned long long estS; // estimator: exact state after the head segment
+    uint32_t estC;
+    int32_t estFallbacks;    // segments the estimator had to walk node by node (diagnostic)
     uint8_t distanceMap[VR_MAX_DEPTH + 8];
 };
 

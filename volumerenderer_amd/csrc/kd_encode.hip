@@ -99,72 +99,210 @@ __global__ void k_ctrl_init(Ctrl *ctrls)
     c.cur = 0; c.prev = 1; c.pendingEqual = 0;
     c.par = 0; c.ra = 1; c.rb = 2;
     c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0;
+    c.estS = 0; c.estC = 0; c.estTbase = 0; c.estFallbacks = 0;
     for (int i = 0; i < VR_MAX_DEPTH + 8; ++i) c.distanceMap[i] = 0;
 }
 
-// Running-mean start distance (R.cpp:254-266, encodeNodeEstimate R.cpp:415-455).
-// The filter state (S,C) feeds back into every decision, so the level is walked in
-// order by ONE wave per brick: 64 nodes per step, each lane deciding from the exact
-// integer closed form
-//     counted <=> pd>0 && ( S < pd*(2C+1) || (t>p && 2t-p>255) || (t<p && 2t<p) )
-// with (S,C) = carried state + prefix over the lower lanes' decisions; the ballot is
-// iterated to its fixed point, which equals the serial result by induction on lanes.
-__global__ void __launch_bounds__(64)
-k_estimate(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
-           int64_t leafStride)
+// ---- running-mean start distance (R.cpp:254-266, encodeNodeEstimate R.cpp:415-455) ----
+// The filter state (S,C) feeds back into every decision:
+//     counted <=> pd>0 && ( S < pd*(2C+1) || (t>p && 2t-p>255) || (t<p && 2t<p) )      (*)
+// (exact integer form of the reference's double arithmetic; S = sum of counted pd,
+// C = their count, pd = |parent - truth|).  Plain fixed-point iteration over the whole
+// level does not converge quickly (a flipped decision perturbs every later one), so
+// the level is processed in three steps that are exact by construction:
+//   k_est_head  one wave walks the first EST_HEAD nodes in order (64 nodes per step,
+//               ballot iterated to its fixed point = the serial result by induction
+//               on lanes) and fixes a window of EST_CAND candidate thresholds.
+//   k_est_summ  fully parallel: for every later segment of EST_SEG nodes and every
+//               candidate T, the sums the segment would add IF floor(S/(2C+1)) == T
+//               held at every node of it (then (*) reduces to pd > T), plus two
+//               bounds A,B such that the hypothesis is true for a start state (S0,C0)
+//               whenever  S0 - T(2C0+1) >= A  and  S0 - (T+1)(2C0+1) < B.
+//   k_est_walk  one wave carries the exact (S,C) through the segments, 64 per step:
+//               prefix-sums the hypothesised sums, checks A/B for every segment with
+//               its exact start state, commits up to the first failure and walks only
+//               that segment node by node.
+#define EST_SEG 1024
+#define EST_CAND 8
+#define EST_HEAD 4096
+
+struct EstSummary { uint32_t sumS[EST_CAND], sumC[EST_CAND]; int32_t A[EST_CAND], B[EST_CAND]; };
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
-    const int brick = blockIdx.x;
-    Ctrl &c = ctrls[brick];
-    const int lane = threadIdx.x;
-    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
-    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
-    const uint32_t n = 1u << d;
-    unsigned long long S = 0;
-    uint32_t C = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
+    for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(v, o); if (lane >= o) v += u; }
+    return v;
+}
+
+// exact in-order walk of nodes [lo, hi) by one wave; (S,C) are wave-uniform
+__device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, uint32_t lo,
+                                       uint32_t hi, unsigned long long &S, uint32_t &C, int lane)
+{
+    for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t i = base + lane;
-        bool valid = i < n;
+        bool valid = i < hi;
         int t = valid ? T[i] : 0;
         int p = (valid && d > 0) ? P[i >> 1] : 0;
         int pd = p > t ? p - t : t - p;
         bool forced = (t > p && 2 * t - p > 255) || (t < p && 2 * t < p);
         bool cand = valid && pd > 0;
-        bool dec = cand;
-        unsigned long long mask;
-        uint32_t spre = 0;
+        // first guess: the threshold at the chunk start
+        bool dec = cand && (forced || S < (unsigned long long)pd * (2ull * C + 1ull));
+        unsigned long long mask = __ballot(dec);
         for (int it = 0; it < 65; ++it) {
-            mask = __ballot(dec);
             uint32_t cpre = __popcll(mask & ((1ull << lane) - 1ull));
             uint32_t v = dec ? (uint32_t)pd : 0u;
-            uint32_t incl = v;
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t u = __shfl_up(incl, o);
-                if (lane >= o) incl += u;
-            }
-            spre = incl - v;
-            unsigned long long Si = S + spre;
-            unsigned long long rhs = (unsigned long long)pd * (2ull * (C + cpre) + 1ull);
-            bool nd = cand && (forced || Si < rhs);
+            uint32_t spre = wave_incl_scan_u32(v, lane) - v;
+            bool nd = cand && (forced || (S + spre) < (unsigned long long)pd * (2ull * (C + cpre) + 1ull));
             unsigned long long nmask = __ballot(nd);
             dec = nd;
             if (nmask == mask) break;
+            mask = nmask;
         }
         uint32_t v = dec ? (uint32_t)pd : 0u;
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         S += v;
         C += __popcll(mask);
     }
+}
+
+__device__ inline void est_finish(Ctrl &c, unsigned long long S, uint32_t C, int maxEpochs)
+{
+    c.currentDistance = C > 0 ? round((double)S / (double)C) : 0.0; // R.cpp:263-266
+    c.previousDistance = 0.0;  // R.cpp:272-274
+    c.previousStepSize = 255.0;
+    c.previousError = 65025.0;
+    c.epoch = 0;
+    c.active = maxEpochs > 0 ? 1 : 0;
+    c.fillThisEpoch = c.active;
+    c.errMinus = c.errPlus = 0;
+    c.cur = 0; c.prev = 1; c.pendingEqual = 0;
+}
+
+__global__ void __launch_bounds__(64)
+k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
+           int64_t leafStride)
+{
+    const int brick = blockIdx.x, lane = threadIdx.x;
+    Ctrl &c = ctrls[brick];
+    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
+    const uint32_t n = 1u << d;
+    unsigned long long S = 0;
+    uint32_t C = 0;
+    est_exact_chain(T, P, d, 0, n < EST_HEAD ? n : EST_HEAD, S, C, lane);
     if (lane == 0) {
-        c.currentDistance = C > 0 ? round((double)S / (double)C) : 0.0; // R.cpp:263-266
-        c.previousDistance = 0.0;  // R.cpp:272-274
-        c.previousStepSize = 255.0;
-        c.previousError = 65025.0;
-        c.epoch = 0;
-        c.active = maxEpochs > 0 ? 1 : 0;
-        c.fillThisEpoch = c.active;
-        c.errMinus = c.errPlus = 0;
-        c.cur = 0; c.prev = 1; c.pendingEqual = 0;
+        if (n <= EST_HEAD) est_finish(c, S, C, maxEpochs);
+        else {
+            c.estS = S; c.estC = C;
+            long long Tt = (long long)(S / (2ull * C + 1ull)) - 3;
+            if (Tt < 0) Tt = 0;
+            if (Tt > 255 - (EST_CAND - 1)) Tt = 255 - (EST_CAND - 1);
+            c.estTbase = (int)Tt;
+        }
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_est_summ(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb, int64_t leafStride,
+           EstSummary *__restrict__ summ, int64_t summStride)
+{
+    const int brick = blockIdx.y, lane = threadIdx.x & 63;
+    const Ctrl &c = ctrls[brick];
+    const uint32_t n = 1u << d;
+    const uint32_t seg = EST_HEAD / EST_SEG + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= n / EST_SEG) return;
+    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + (size_t)seg * EST_SEG + lane * 16;
+    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride + (((size_t)seg * EST_SEG + lane * 16) >> 1);
+    const uint4 tv = *(const uint4 *)T;
+    const uint2 pv = *(const uint2 *)P;
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
+    int pd[16];
+    uint32_t forcedMask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int t = (tw[k >> 2] >> ((k & 3) * 8)) & 255, p = (pw[k >> 3] >> (((k >> 1) & 3) * 8)) & 255;
+        pd[k] = p > t ? p - t : t - p;
+        if ((t > p && 2 * t - p > 255) || (t < p && 2 * t < p)) forcedMask |= 1u << k;
+    }
+    const int Tbase = c.estTbase;
+    EstSummary *out = summ + (int64_t)brick * summStride + seg;
+#pragma unroll 1
+    for (int ci = 0; ci < EST_CAND; ++ci) {
+        const int Th = Tbase + ci;
+        int s = 0, cc = 0, a = INT32_MIN, b = INT32_MAX;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int lowv = 2 * Th * cc - s, upv = lowv + 2 * cc;   // at the position BEFORE node k
+            a = lowv > a ? lowv : a;
+            b = upv < b ? upv : b;
+            bool dec = pd[k] > 0 && (((forcedMask >> k) & 1u) || pd[k] > Th);
+            s += dec ? pd[k] : 0;
+            cc += dec ? 1 : 0;
+        }
+        uint32_t si = wave_incl_scan_u32((uint32_t)s, lane), ci2 = wave_incl_scan_u32((uint32_t)cc, lane);
+        int s0 = (int)(si - (uint32_t)s), c0 = (int)(ci2 - (uint32_t)cc);
+        a += 2 * Th * c0 - s0;
+        b += 2 * (Th + 1) * c0 - s0;
+        for (int o = 32; o > 0; o >>= 1) {
+            int ua = __shfl_xor(a, o), ub = __shfl_xor(b, o);
+            a = ua > a ? ua : a;
+            b = ub < b ? ub : b;
+        }
+        uint32_t totS = __shfl(si, 63), totC = __shfl(ci2, 63);
+        if (lane == 0) { out->sumS[ci] = totS; out->sumC[ci] = totC; out->A[ci] = a; out->B[ci] = b; }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_est_walk(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
+           int64_t leafStride, const EstSummary *__restrict__ summ, int64_t summStride)
+{
+    const int brick = blockIdx.x, lane = threadIdx.x;
+    Ctrl &c = ctrls[brick];
+    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
+    const uint32_t n = 1u << d, nseg = n / EST_SEG;
+    const EstSummary *sm = summ + (int64_t)brick * summStride;
+    unsigned long long S = c.estS;
+    uint32_t C = c.estC;
+    const int Tbase = c.estTbase;
+    long long Tc = (long long)(S / (2ull * C + 1ull));
+    uint32_t seg = EST_HEAD / EST_SEG;
+    int fallbacks = 0;
+    while (seg < nseg) {
+        const long long ci = Tc - Tbase;
+        if (ci < 0 || ci >= EST_CAND) {      // threshold left the candidate window: walk the rest in order
+            est_exact_chain(T, P, d, seg * EST_SEG, n, S, C, lane);
+            fallbacks += (int)(nseg - seg);
+            break;
+        }
+        const uint32_t k = seg + lane;
+        const bool valid = k < nseg;
+        uint32_t ss = 0, sc = 0;
+        int A = INT32_MIN, B = INT32_MAX;
+        if (valid) { ss = sm[k].sumS[ci]; sc = sm[k].sumC[ci]; A = sm[k].A[ci]; B = sm[k].B[ci]; }
+        const uint32_t si = wave_incl_scan_u32(ss, lane), sci = wave_incl_scan_u32(sc, lane);
+        const long long S0 = (long long)S + (long long)(si - ss);
+        const long long q = 2ll * ((long long)C + (long long)(sci - sc)) + 1ll;
+        const bool ok = !valid || (S0 - Tc * q >= (long long)A && S0 - (Tc + 1) * q < (long long)B);
+        const unsigned long long bad = ~__ballot(ok);
+        if (bad == 0ull) {
+            S += __shfl(si, 63);
+            C += __shfl(sci, 63);
+            seg += 64;
+            continue;
+        }
+        const int f = __ffsll((long long)bad) - 1;            // first segment whose hypothesis fails
+        S += __shfl(si - ss, f);
+        C += __shfl(sci - sc, f);
+        seg += f;
+        est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane);
+        Tc = (long long)(S / (2ull * C + 1ull));
+        seg += 1;
+        ++fallbacks;
+    }
+    if (lane == 0) { est_finish(c, S, C, maxEpochs); c.estFallbacks += fallbacks; }
 }
 
 __device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
@@ -226,47 +364,94 @@ k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict
     }
 }
 
-// End of epoch e and head of epoch e+1 of the while loop at R.cpp:275-366, one thread
+// End of epoch e and head of epoch e+1 of the while loop at R.cpp:275-366, one wave
 // per brick.  `currentError += err^2` runs over the level in node order starting from
 // a fractional carry (defect C-1), so the double rounds only when the running sum
-// crosses a power of two: block partials are added whole while the sum provably stays
-// inside its binade (every partial sum is then exactly representable) and node by
-// node inside the block where it crosses.
-__global__ void k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restrict__ temp,
-                          int64_t heapStride, ReconBufs rb, int64_t leafStride,
-                          const unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+// crosses a power of two: while the sum provably stays inside its binade every partial
+// sum is exactly representable, so whole block partials (64 per step, prefix-summed
+// across the wave) are added at once; the block in which the sum crosses is walked
+// node by node with the reference's own rounded additions.
+__device__ __forceinline__ double next_pow2_above(double s)
 {
-    if (threadIdx.x) return;
-    const int brick = blockIdx.x;
+    int ex;
+    frexp(s, &ex);              // s in [2^(ex-1), 2^ex)
+    return ldexp(1.0, ex);
+}
+
+__device__ inline double ctl_walk_block(double s, const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d,
+                                        int dist, uint32_t lo, uint32_t hi, int lane)
+{
+    for (uint32_t base = lo; base < hi; base += 64) {
+        uint32_t i = base + lane;
+        uint32_t e = 0;
+        if (i < hi) {
+            int t = T[i], p = d > 0 ? P[i >> 1] : 0;
+            int er = encode_node(t, p, dist).err;
+            e = (uint32_t)(er * er);
+        }
+        const uint32_t incl = wave_incl_scan_u32(e, lane);
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t consumed = 0;
+        int start = 0;
+        while (true) {
+            bool ok = true;
+            if (lane >= start && s != 0.0) ok = (s + (double)(incl - consumed)) < next_pow2_above(s);
+            const unsigned long long bad = ~__ballot(ok);
+            if (bad == 0ull) { s = s + (double)(total - consumed); break; }
+            const int f = __ffsll((long long)bad) - 1;
+            const uint32_t exclF = __shfl(incl - e, f), eF = __shfl(e, f);
+            s = s + (double)(exclF - consumed);   // exact: still inside the binade
+            s = s + (double)eF;                   // the reference's rounded add that crosses it
+            consumed = exclF + eF;
+            start = f + 1;
+        }
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(64)
+k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride,
+          ReconBufs rb, int64_t leafStride, const unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+{
+    const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
     const uint32_t n = 1u << d;
-    if (c.active && c.fillThisEpoch) {
+    const bool ending = c.active && c.fillThisEpoch;
+    double s = c.currentError;
+    if (ending) {
         const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
         const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
         const int dist = (int)(uint8_t)c.currentDistance;
         const uint32_t nblk = (n + FILL_NODES_PER_BLOCK - 1) / FILL_NODES_PER_BLOCK;
-        double s = c.currentError;
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
-            unsigned long long e2 = blockErr[(int64_t)brick * nErrBlk + blk];
-            if (e2 == 0) continue;
-            bool whole = false;
-            double cand = s + (double)e2;
-            if (s == 0.0) whole = true;            // integers below 2^53: exact
-            else {
-                int ex;
-                frexp(s, &ex);                     // s in [2^(ex-1), 2^ex)
-                whole = cand < ldexp(1.0, ex);     // stays in the binade -> exact
-            }
-            if (whole) { s = cand; continue; }
-            uint32_t lo = blk * FILL_NODES_PER_BLOCK, hi = lo + FILL_NODES_PER_BLOCK;
-            if (hi > n) hi = n;
-            for (uint32_t i = lo; i < hi; ++i) {
-                int t = T[i];
-                int p = d > 0 ? P[i >> 1] : 0;
-                int er = encode_node(t, p, dist).err;
-                s += (double)(er * er);
+        const unsigned long long *be = blockErr + (int64_t)brick * nErrBlk;
+        for (uint32_t base = 0; base < nblk; base += 64) {
+            const uint32_t blk = base + lane;
+            const unsigned long long e2 = blk < nblk ? be[blk] : 0ull;
+            unsigned long long incl = e2;
+            for (int o = 1; o < 64; o <<= 1) { unsigned long long u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            const unsigned long long total = __shfl(incl, 63);
+            unsigned long long consumed = 0;
+            int start = 0;
+            while (true) {
+                bool ok = true;
+                // an integer-valued sum below 2^53 adds integers exactly whatever the binade
+                const bool sInt = (s == floor(s)) && (s + (double)(total - consumed)) < 9007199254740992.0;
+                if (lane >= start && !sInt) ok = (s + (double)(incl - consumed)) < next_pow2_above(s);
+                const unsigned long long bad = ~__ballot(ok);
+                if (bad == 0ull) { s = s + (double)(total - consumed); break; }
+                const int f = __ffsll((long long)bad) - 1;
+                const unsigned long long exclF = __shfl(incl - e2, f), inclF = __shfl(incl, f);
+                s = s + (double)(exclF - consumed);
+                uint32_t lo = (base + f) * FILL_NODES_PER_BLOCK, hi = lo + FILL_NODES_PER_BLOCK;
+                if (hi > n) hi = n;
+                s = ctl_walk_block(s, T, P, d, dist, lo, hi, lane);
+                consumed = inclF;
+                start = f + 1;
             }
         }
+    }
+    if (lane != 0) return;
+    if (ending) {
         c.currentError = s / (double)n;                        // R.cpp:315
         if (c.currentError < 1.0) {                            // R.cpp:319
             c.active = 0;
@@ -350,7 +535,8 @@ k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint
         }
     }
     for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(err, o); err = u > err ? u : err; }
-    if ((threadIdx.x & 63) == 0 && err > 0) atomicMax(&c.maxErrBefore, err); // R.cpp:71-76
+    // one contended atomic per wave would serialise the whole grid: only waves that raise the max try
+    if ((threadIdx.x & 63) == 0 && err > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, err); // R.cpp:71-76
 }
 
 __global__ void __launch_bounds__(256)
@@ -451,6 +637,7 @@ struct EmitArgs {
     int64_t heapStride, leafStride;
     int D, maxDepth, tol, Ds, K;
     uint32_t *blockTot, *blockOff;
+    unsigned long long *blockL1;   // per-block sum |recon - temp| after growth (reduced by k_emit_stats)
     int64_t nEmitBlk;
     uint8_t *tree, *treeR;
     int64_t treeCap;
@@ -561,6 +748,7 @@ k_emit_write(EmitArgs a)
 {
     __shared__ uint32_t shw[4];
     __shared__ uint32_t W[EMIT_LDS_WORDS], WR[EMIT_LDS_WORDS];
+    __shared__ unsigned long long shl1[4];
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
     const bool mr = a.codesR != nullptr;
@@ -608,10 +796,11 @@ k_emit_write(EmitArgs a)
     unsigned long long l1 = (unsigned long long)fe;
     for (int q = 32; q > 0; q >>= 1) { int u = __shfl_xor(fe, q); fe = u > fe ? u : fe; l1 += __shfl_xor(l1, q); }
     if ((threadIdx.x & 63) == 0) {
-        if (fe > 0) atomicMax(&c.maxErrAfter, fe);
-        if (l1) atomicAdd(&c.statL1, l1);
+        if (fe > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, fe);
+        shl1[threadIdx.x >> 6] = l1;
     }
     __syncthreads();
+    if (threadIdx.x == 0) a.blockL1[(int64_t)brick * a.nEmitBlk + blockIdx.x] = shl1[0] + shl1[1] + shl1[2] + shl1[3];
     if (tot == 0) return;
     uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
     uint32_t *GR = mr ? (uint32_t *)(a.treeR + (int64_t)brick * a.treeCap) + (g0 >> 4) : nullptr;
@@ -620,6 +809,19 @@ k_emit_write(EmitArgs a)
         if (i == 0 || i == nw - 1) { if (W[i]) atomicOr(&G[i], W[i]); if (mr && WR[i]) atomicOr(&GR[i], WR[i]); }
         else { G[i] = W[i]; if (mr) GR[i] = WR[i]; }
     }
+}
+
+__global__ void __launch_bounds__(1024)
+k_emit_stats(EmitArgs a, int64_t nblk)
+{
+    __shared__ unsigned long long sh[16];
+    const int brick = blockIdx.x;
+    unsigned long long v = 0;
+    for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) v += a.blockL1[(int64_t)brick * a.nEmitBlk + i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += sh[i]; a.ctrls[brick].statL1 = t; }
 }
 
 // ------------------------------------------------------------ host driver ----
@@ -637,8 +839,15 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
     }
     for (int d = 0; d <= D; ++d) {
         const int64_t n = (int64_t)1 << d;
-        hipLaunchKernelGGL(k_estimate, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride, rb,
+        hipLaunchKernelGGL(k_est_head, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride, rb,
                            bs->leafStride);
+        if (n > EST_HEAD) {
+            const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
+            hipLaunchKernelGGL(k_est_summ, dim3(cdiv(nseg, 4), B), dim3(256), 0, st, d, s.ctrl, s.temp, bs->heapStride,
+                               rb, bs->leafStride, (EstSummary *)bs->estSumm, bs->estSummStride);
+            hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride,
+                               rb, bs->leafStride, (const EstSummary *)bs->estSumm, bs->estSummStride);
+        }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
                                s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
@@ -714,6 +923,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.heapStride = bs->heapStride; a.leafStride = bs->leafStride;
     a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
+    a.blockL1 = bs->blockL1;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
     const int64_t nblk = cdiv((int64_t)1 << D, EMIT_RANKS_PER_BLOCK);
@@ -721,6 +931,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
     hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, nblk);
     hipEventRecord(bs->ev[4], st);
     return launch_status("encode");
 }
