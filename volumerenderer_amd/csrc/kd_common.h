@@ -57,6 +57,8 @@ struct Ctrl {
     unsigned long long estS; // estimator: exact state after the head segment
     uint32_t estC;
     int32_t estFallbacks;    // segments the estimator had to walk node by node (diagnostic)
+    int32_t estSeg;          // estimator: next segment to verify
+    int32_t estDone;         // estimator: level finished
     uint8_t distanceMap[VR_MAX_DEPTH + 8];
 };
 

@@ -99,7 +99,7 @@ __global__ void k_ctrl_init(Ctrl *ctrls)
     c.cur = 0; c.prev = 1; c.pendingEqual = 0;
     c.par = 0; c.ra = 1; c.rb = 2;
     c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0;
-    c.estS = 0; c.estC = 0; c.estTbase = 0; c.estFallbacks = 0;
+    c.estS = 0; c.estC = 0; c.estTbase = 0; c.estFallbacks = 0; c.estSeg = 0; c.estDone = 0;
     for (int i = 0; i < VR_MAX_DEPTH + 8; ++i) c.distanceMap[i] = 0;
 }
 
@@ -123,10 +123,12 @@ __global__ void k_ctrl_init(Ctrl *ctrls)
 //               its exact start state, commits up to the first failure and walks only
 //               that segment node by node.
 #define EST_SEG 1024
-#define EST_CAND 8
+#define EST_CAND 16
+#define EST_ROUNDS 3
 #define EST_HEAD 4096
 
 struct EstSummary { uint32_t sumS[EST_CAND], sumC[EST_CAND]; int32_t A[EST_CAND], B[EST_CAND]; };
+static_assert(sizeof(EstSummary) == 16 * EST_CAND, "EstSummary layout");
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
@@ -166,6 +168,15 @@ __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint
     }
 }
 
+// candidate window [base, base+EST_CAND) around the current threshold
+__device__ inline int est_window_base(long long T)
+{
+    long long b = T - EST_CAND / 3;
+    if (b < 0) b = 0;
+    if (b > 256 - EST_CAND) b = 256 - EST_CAND;
+    return (int)b;
+}
+
 __device__ inline void est_finish(Ctrl &c, unsigned long long S, uint32_t C, int maxEpochs)
 {
     c.currentDistance = C > 0 ? round((double)S / (double)C) : 0.0; // R.cpp:263-266
@@ -195,10 +206,9 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
         if (n <= EST_HEAD) est_finish(c, S, C, maxEpochs);
         else {
             c.estS = S; c.estC = C;
-            long long Tt = (long long)(S / (2ull * C + 1ull)) - 3;
-            if (Tt < 0) Tt = 0;
-            if (Tt > 255 - (EST_CAND - 1)) Tt = 255 - (EST_CAND - 1);
-            c.estTbase = (int)Tt;
+            c.estSeg = EST_HEAD / EST_SEG;
+            c.estDone = 0;
+            c.estTbase = est_window_base((long long)(S / (2ull * C + 1ull)));
         }
     }
 }
@@ -211,7 +221,7 @@ k_est_summ(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStr
     const Ctrl &c = ctrls[brick];
     const uint32_t n = 1u << d;
     const uint32_t seg = EST_HEAD / EST_SEG + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (seg >= n / EST_SEG) return;
+    if (c.estDone || seg < (uint32_t)c.estSeg || seg >= n / EST_SEG) return;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + (size_t)seg * EST_SEG + lane * 16;
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride + (((size_t)seg * EST_SEG + lane * 16) >> 1);
     const uint4 tv = *(const uint4 *)T;
@@ -255,7 +265,7 @@ k_est_summ(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStr
 }
 
 __global__ void __launch_bounds__(64)
-k_est_walk(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
+k_est_walk(int d, int maxEpochs, int lastRound, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
            int64_t leafStride, const EstSummary *__restrict__ summ, int64_t summStride)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
@@ -264,16 +274,25 @@ k_est_walk(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
     const uint32_t n = 1u << d, nseg = n / EST_SEG;
     const EstSummary *sm = summ + (int64_t)brick * summStride;
+    if (c.estDone) return;
     unsigned long long S = c.estS;
     uint32_t C = c.estC;
     const int Tbase = c.estTbase;
     long long Tc = (long long)(S / (2ull * C + 1ull));
-    uint32_t seg = EST_HEAD / EST_SEG;
+    uint32_t seg = (uint32_t)c.estSeg;
     int fallbacks = 0;
     while (seg < nseg) {
         const long long ci = Tc - Tbase;
-        if (ci < 0 || ci >= EST_CAND) {      // threshold left the candidate window: walk the rest in order
-            est_exact_chain(T, P, d, seg * EST_SEG, n, S, C, lane);
+        if (ci < 0 || ci >= EST_CAND) {      // threshold left the candidate window
+            if (!lastRound) {                // next round: new summaries around the new threshold
+                if (lane == 0) {
+                    c.estS = S; c.estC = C; c.estSeg = (int)seg;
+                    c.estTbase = est_window_base(Tc);
+                    c.estFallbacks += fallbacks;
+                }
+                return;
+            }
+            est_exact_chain(T, P, d, seg * EST_SEG, n, S, C, lane);   // last resort: walk the rest in order
             fallbacks += (int)(nseg - seg);
             break;
         }
@@ -302,7 +321,7 @@ k_est_walk(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
         seg += 1;
         ++fallbacks;
     }
-    if (lane == 0) { est_finish(c, S, C, maxEpochs); c.estFallbacks += fallbacks; }
+    if (lane == 0) { est_finish(c, S, C, maxEpochs); c.estFallbacks += fallbacks; c.estDone = 1; }
 }
 
 __device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
@@ -843,10 +862,13 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
                            bs->leafStride);
         if (n > EST_HEAD) {
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
-            hipLaunchKernelGGL(k_est_summ, dim3(cdiv(nseg, 4), B), dim3(256), 0, st, d, s.ctrl, s.temp, bs->heapStride,
-                               rb, bs->leafStride, (EstSummary *)bs->estSumm, bs->estSummStride);
-            hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride,
-                               rb, bs->leafStride, (const EstSummary *)bs->estSumm, bs->estSummStride);
+            for (int r = 0; r < EST_ROUNDS; ++r) {
+                hipLaunchKernelGGL(k_est_summ, dim3(cdiv(nseg, 4), B), dim3(256), 0, st, d, s.ctrl, s.temp,
+                                   bs->heapStride, rb, bs->leafStride, (EstSummary *)bs->estSumm, bs->estSummStride);
+                hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, r == EST_ROUNDS - 1 ? 1 : 0,
+                                   s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
+                                   (const EstSummary *)bs->estSumm, bs->estSummStride);
+            }
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
