@@ -154,7 +154,7 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     if (b.D > 28) { delete h; return VR_ERR_UNSUPPORTED; }
     b.maxDepth = b.D + VR_CHAIN_LEVELS;
     b.tolerance = tolerance; b.maxEpochs = max_epochs; b.variant = variant;
-    b.K = b.D < 9 ? b.D : 9;
+    b.K = b.D < 6 ? b.D : 6;   // decode index granularity: 4x4x4 voxel subtrees
     b.Ds = b.D - b.K;
     b.heapStride = (int64_t)1 << (b.D + 1);
     b.leafStride = (int64_t)1 << b.D;

@@ -119,15 +119,181 @@ k_decode_lane(DecodeArgs a)
     }
 }
 
+// ---- v2: tile decode --------------------------------------------------------------
+// One lane decodes one depth-(D-6) subtree = a 4x4x4 voxel block (64 leaves, up to
+// ~600 tokens).  A wave takes 32x2x1 such blocks = a 128x8x4 voxel tile whose rows are
+// whole 128-byte lines of the output volume.  Lanes emit their leaves in stream (Morton)
+// order, four per dword, into an LDS tile laid out [dword q][lane] (bank = lane, so
+// the divergent walk writes conflict-free); the wave then gathers 16-byte row pieces
+// from it and stores 8 full lines per instruction.  Requirements: the six deepest
+// split levels cycle through x,y,z twice (any order) and X>=128, Y>=8, Z>=4;
+// everything else takes k_decode_lane.
+struct TileArgs {
+    const uint8_t *tree;
+    int64_t treeCap;
+    const uint32_t *idxOff;
+    const uint8_t *idxVal;
+    int64_t nIdx;
+    const Ctrl *ctrls;
+    uint8_t *out;
+    Geom g;
+    int D, Ds;
+    int jx, jy, jz;          // position of each axis among the three deepest split levels (0 = deepest)
+    int tilesX, tilesY, tilesZ;
+};
+
+#define DEC_WAVES 4
+
+__device__ __forceinline__ int lds_rot(int q) { return ((q & 1) + ((q >> 1) & 1) + ((q >> 2) & 1) + 2 * ((q >> 3) & 1)) & 3; }
+
+__global__ void __launch_bounds__(64 * DEC_WAVES)
+k_decode_tile(TileArgs a)
+{
+    __shared__ uint32_t tileS[DEC_WAVES][16 * 64];
+    __shared__ uint8_t stkS[DEC_WAVES][8 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int brick = blockIdx.y;
+    const int tileId = blockIdx.x * DEC_WAVES + wave;
+    if (tileId >= a.tilesX * a.tilesY * a.tilesZ) return;
+    const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
+    uint32_t *tile = tileS[wave];
+    uint8_t *stk = stkS[wave];
+    const uint8_t *dmap = a.ctrls[brick].distanceMap;
+
+    // ---- which subtree is mine
+    int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};   // subtree coords (units of 4 voxels)
+    uint32_t s = 0;
+    for (int d = 0; d < a.Ds; ++d) s = (s << 1) | ((uint32_t)(sc[a.g.axis[d]] >> (a.g.bit[d] - 2)) & 1u);
+    const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
+    const int val0 = a.idxVal[(int64_t)brick * a.nIdx + s];
+
+    // ---- walk my token run, leaves out in Morton order
+    if (off == VR_IDX_DEAD) {
+        const uint32_t vv = (uint32_t)val0 * 0x01010101u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[q * 64 + ((lane + lds_rot(q)) & 63)] = vv;
+    } else {
+        const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
+        uint32_t wi = off >> 4;
+        const int sh0 = (int)(off & 15u) * 2;
+        unsigned long long buf = ((unsigned long long)W[wi] | ((unsigned long long)W[wi + 1] << 32)) >> sh0;
+        int nb = 64 - sh0;
+        wi += 2;
+        int j = 0, q = 0, na = 0;
+        uint32_t path = 0, acc = 0;
+        int v = val0;
+        while (true) {
+            int tok = (int)(buf & 3ull);
+            buf >>= 2; nb -= 2;
+            if (nb <= 32) { buf |= (unsigned long long)W[wi++] << nb; nb += 32; }
+            if (j > 0) v = apply_code(stk[(j - 1) * 64 + lane], tok, dmap[a.Ds + j]);
+            bool terminal = false;
+            if (tok == 3) {
+                const int leaves = 1 << (6 - j);
+                if (leaves >= 4) {
+                    const uint32_t vv = (uint32_t)v * 0x01010101u;
+                    for (int k = 0; k < (leaves >> 2); ++k, ++q) tile[q * 64 + ((lane + lds_rot(q)) & 63)] = vv;
+                } else {
+                    for (int k = 0; k < leaves; ++k) { acc |= (uint32_t)v << (8 * na); ++na; }
+                }
+                terminal = true;
+            } else if (j == 6) {
+                for (int c = 1; c <= VR_CHAIN_LEVELS; ++c) {   // grown branch: same voxel, distances 64..1
+                    int t2 = (int)(buf & 3ull);
+                    buf >>= 2; nb -= 2;
+                    if (nb <= 32) { buf |= (unsigned long long)W[wi++] << nb; nb += 32; }
+                    if (t2 == 3) break;
+                    v = apply_code(v, t2, dmap[a.D + c]);
+                }
+                acc |= (uint32_t)v << (8 * na); ++na;
+                terminal = true;
+            }
+            if (na == 4) { tile[q * 64 + ((lane + lds_rot(q)) & 63)] = acc; ++q; acc = 0; na = 0; }
+            if (terminal) {
+                while (j > 0 && (path & 1u)) { path >>= 1; --j; }
+                if (j == 0) break;
+                path |= 1u;
+            } else { stk[j * 64 + lane] = (uint8_t)v; ++j; path <<= 1; }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- gather 16-byte row pieces and store whole 128-byte lines
+    const int jx = a.jx, jy = a.jy, jz = a.jz;
+    const int c = lane & 7;
+    uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int R = st * 8 + (lane >> 3);
+        const int y = R & 7, z = R >> 3;
+        const int dy = y & 3, dz = z & 3;
+        const int rb = ((dy & 1) << jy) | ((dy >> 1) << (3 + jy)) | ((dz & 1) << jz) | ((dz >> 1) << (3 + jz));
+        const int q0 = rb >> 2, b0 = rb & 3;
+        const int lsBase = 4 * c + 32 * (y >> 2);
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int Ls = lsBase + k;
+            if (jx == 0) {          // dx0 -> byte +1, dx1 -> dword +2
+                uint32_t A = tile[q0 * 64 + ((Ls + lds_rot(q0)) & 63)], B = tile[(q0 + 2) * 64 + ((Ls + lds_rot(q0 + 2)) & 63)];
+                uint32_t lo = (A >> (8 * b0)) & 0xFFFFu, hi = (B >> (8 * b0)) & 0xFFFFu;
+                o[k] = lo | (hi << 16);
+            } else if (jx == 1) {   // dx0 -> byte +2, dx1 -> dword +4
+                uint32_t A = tile[q0 * 64 + ((Ls + lds_rot(q0)) & 63)], B = tile[(q0 + 4) * 64 + ((Ls + lds_rot(q0 + 4)) & 63)];
+                uint32_t a0 = (A >> (8 * b0)) & 0xFFu, a1 = (A >> (8 * b0 + 16)) & 0xFFu;
+                uint32_t c0 = (B >> (8 * b0)) & 0xFFu, c1 = (B >> (8 * b0 + 16)) & 0xFFu;
+                o[k] = a0 | (a1 << 8) | (c0 << 16) | (c1 << 24);
+            } else {                // dx0 -> dword +1, dx1 -> dword +8
+                uint32_t A = tile[q0 * 64 + ((Ls + lds_rot(q0)) & 63)], B = tile[(q0 + 1) * 64 + ((Ls + lds_rot(q0 + 1)) & 63)];
+                uint32_t C2 = tile[(q0 + 8) * 64 + ((Ls + lds_rot(q0 + 8)) & 63)], D2 = tile[(q0 + 9) * 64 + ((Ls + lds_rot(q0 + 9)) & 63)];
+                o[k] = ((A >> (8 * b0)) & 0xFFu) | (((B >> (8 * b0)) & 0xFFu) << 8) | (((C2 >> (8 * b0)) & 0xFFu) << 16) |
+                       (((D2 >> (8 * b0)) & 0xFFu) << 24);
+            }
+        }
+        const int64_t gy = (int64_t)ty * 8 + y, gz = (int64_t)tz * 4 + z;
+        *(uint4 *)(O + (int64_t)a.g.X * (gy + (int64_t)a.g.Y * gz)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static bool tile_geometry(const BrickSet *bs, TileArgs &a)
+{
+    const Geom &g = bs->g;
+    if (bs->K != 6 || g.D < 6 || g.X < 128 || g.Y < 8 || g.Z < 4) return false;
+    const int D = g.D;
+    int seen = 0;
+    for (int q = 0; q < 3; ++q) {
+        if (g.axis[D - 6 + q] != g.axis[D - 3 + q]) return false;
+        if (g.bit[D - 6 + q] != 1 || g.bit[D - 3 + q] != 0) return false;
+        seen |= 1 << g.axis[D - 3 + q];
+    }
+    if (seen != 7) return false;
+    int pos[3];
+    for (int q = 0; q < 3; ++q) pos[g.axis[D - 3 + q]] = 2 - q;   // deepest level -> rank bit 0
+    a.jx = pos[0]; a.jy = pos[1]; a.jz = pos[2];
+    a.tilesX = g.X / 128; a.tilesY = g.Y / 8; a.tilesZ = g.Z / 4;
+    return true;
+}
+
 int decode_launch(BrickSet *bs, uint8_t *out, hipStream_t st)
 {
-    DecodeArgs a;
-    a.tree = bs->mid.tree; a.treeCap = bs->treeCap;
-    a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
-    a.ctrls = bs->mid.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
-    a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
     hipEventRecord(bs->ev[5], st);
-    hipLaunchKernelGGL(k_decode_lane, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
+    TileArgs t;
+    if (!getenv("VRHIP_DECODE_V1") && tile_geometry(bs, t)) {
+        t.tree = bs->mid.tree; t.treeCap = bs->treeCap;
+        t.idxOff = bs->idxOff; t.idxVal = bs->idxVal; t.nIdx = bs->nIdx;
+        t.ctrls = bs->mid.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
+        const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
+        hipLaunchKernelGGL(k_decode_tile, dim3((unsigned)((ntiles + DEC_WAVES - 1) / DEC_WAVES), bs->B),
+                           dim3(64 * DEC_WAVES), 0, st, t);
+    } else {
+        DecodeArgs a;
+        a.tree = bs->mid.tree; a.treeCap = bs->treeCap;
+        a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
+        a.ctrls = bs->mid.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
+        a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
+        hipLaunchKernelGGL(k_decode_lane, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
+    }
     hipEventRecord(bs->ev[6], st);
     return launch_status("decode");
 }
