@@ -144,21 +144,29 @@ struct TileArgs {
 
 #define DEC_WAVES 4
 
-__device__ __forceinline__ int lds_rot(int q) { return ((q & 1) + ((q >> 1) & 1) + ((q >> 2) & 1) + 2 * ((q >> 3) & 1)) & 3; }
+// rotation of the lane index inside dword row q of the LDS tile (see the gather stage): (q0+q1+q2+2*q3)&3, as a packed table
+__device__ __forceinline__ int lds_rot(int q) { return (int)((0x433EE994u >> (2 * q)) & 3u); }
 
 __global__ void __launch_bounds__(64 * DEC_WAVES)
 k_decode_tile(TileArgs a)
 {
     __shared__ uint32_t tileS[DEC_WAVES][16 * 64];
     __shared__ uint8_t stkS[DEC_WAVES][8 * 64];
+    __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * DEC_WAVES + wave;
-    if (tileId >= a.tilesX * a.tilesY * a.tilesZ) return;
     const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
     uint32_t *tile = tileS[wave];
     uint8_t *stk = stkS[wave];
-    const uint8_t *dmap = a.ctrls[brick].distanceMap;
+    const bool tileValid = tileId < a.tilesX * a.tilesY * a.tilesZ;
+    if (threadIdx.x < 16) {
+        const uint8_t *dmap = a.ctrls[brick].distanceMap;
+        const int t = threadIdx.x;
+        dmS[t] = t == 0 ? 0 : (t < 8 ? dmap[a.Ds + (t < 7 ? t : 0)] : dmap[a.D + (t - 8)]);   // [0] = 0: the subtree root keeps the index value
+    }
+    __syncthreads();
+    if (!tileValid) return;
 
     // ---- which subtree is mine
     int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};   // subtree coords (units of 4 voxels)
@@ -167,53 +175,79 @@ k_decode_tile(TileArgs a)
     const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
     const int val0 = a.idxVal[(int64_t)brick * a.nIdx + s];
 
-    // ---- walk my token run, leaves out in Morton order
+    // ---- walk my token run, leaves out in Morton order.
+    // One action per iteration and lane (consume one token, or write one dword of a
+    // pruned node's fill), so the wave runs a short uniform loop body instead of nested
+    // divergent loops.  Tokens come from a 64-bit buffer topped up with one 32-bit word
+    // every 16 iterations: a lane consumes at most 16 tokens per block, so >= 32 valid
+    // bits at block start can never underflow, and the word loaded at block start is only
+    // merged at block end -- its global-memory latency hides behind the 16 iterations.
     if (off == VR_IDX_DEAD) {
         const uint32_t vv = (uint32_t)val0 * 0x01010101u;
 #pragma unroll
         for (int q = 0; q < 16; ++q) tile[q * 64 + ((lane + lds_rot(q)) & 63)] = vv;
-    } else {
+    }
+    {
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
-        uint32_t wi = off >> 4;
-        const int sh0 = (int)(off & 15u) * 2;
+        bool done = off == VR_IDX_DEAD;
+        const uint32_t o0 = done ? 0u : off;
+        uint32_t wi = o0 >> 4;
+        const int sh0 = (int)(o0 & 15u) * 2;
         unsigned long long buf = ((unsigned long long)W[wi] | ((unsigned long long)W[wi + 1] << 32)) >> sh0;
         int nb = 64 - sh0;
         wi += 2;
-        int j = 0, q = 0, na = 0;
-        uint32_t path = 0, acc = 0;
+        uint32_t p = 1;                 // path with a leading sentinel bit: depth = bitlen(p) - 1
+        int chain = 0;                  // 0: tree token expected, 1..7: next grown-branch step
         int v = val0;
-        while (true) {
-            int tok = (int)(buf & 3ull);
-            buf >>= 2; nb -= 2;
-            if (nb <= 32) { buf |= (unsigned long long)W[wi++] << nb; nb += 32; }
-            if (j > 0) v = apply_code(stk[(j - 1) * 64 + lane], tok, dmap[a.Ds + j]);
-            bool terminal = false;
-            if (tok == 3) {
-                const int leaves = 1 << (6 - j);
-                if (leaves >= 4) {
-                    const uint32_t vv = (uint32_t)v * 0x01010101u;
-                    for (int k = 0; k < (leaves >> 2); ++k, ++q) tile[q * 64 + ((lane + lds_rot(q)) & 63)] = vv;
-                } else {
-                    for (int k = 0; k < leaves; ++k) { acc |= (uint32_t)v << (8 * na); ++na; }
+        int fill = 0, q = 0, na = 0;
+        uint32_t fillv = 0, acc = 0;
+        // value stack rows 0..5 = pushed ancestors, row 6 = scratch for predicated-off pushes,
+        // row 7 = root's "parent" (the index value itself; dmS[0] = 0 leaves it unchanged)
+        stk[7 * 64 + lane] = (uint8_t)val0;
+        while (__ballot(!done) != 0ull) {
+            const uint32_t wn = W[wi];  // consumed (maybe) at the end of this block
+#pragma unroll 1
+            for (int it = 0; it < 16; ++it) {
+                if (done) continue;
+                if (fill > 0) {
+                    tile[q * 64 + ((lane + lds_rot(q)) & 63)] = fillv;
+                    ++q;
+                    if (--fill == 0 && p == 0x80000000u) done = true;
+                    continue;
                 }
-                terminal = true;
-            } else if (j == 6) {
-                for (int c = 1; c <= VR_CHAIN_LEVELS; ++c) {   // grown branch: same voxel, distances 64..1
-                    int t2 = (int)(buf & 3ull);
-                    buf >>= 2; nb -= 2;
-                    if (nb <= 32) { buf |= (unsigned long long)W[wi++] << nb; nb += 32; }
-                    if (t2 == 3) break;
-                    v = apply_code(v, t2, dmap[a.D + c]);
+                // ---- one token, straight-line (selects, no branches)
+                const int tok = (int)(buf & 3ull);
+                buf >>= 2; nb -= 2;
+                const int j = 31 - __clz((int)p);
+                const bool tree = chain == 0;
+                const int sv = stk[(tree ? ((j + 7) & 7) : 7) * 64 + lane];
+                const int dist = dmS[tree ? j : 8 + chain];
+                const int pv = tree ? sv : v;
+                const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+                int nv = pv + delta;
+                nv = nv < 0 ? 0 : (nv > 255 ? 255 : nv);       // decoder step R.cpp:783-787
+                v = nv;
+                const bool is3 = tok == 3;
+                const bool term = is3 || chain == VR_CHAIN_LEVELS;
+                const bool desc = tree && !is3 && j < 6;
+                stk[(desc ? j : 6) * 64 + lane] = (uint8_t)v;
+                const int count = tree ? (64 >> j) : 1;
+                p = desc ? (p << 1) : p;
+                chain = term ? 0 : (tree ? (j == 6 ? 1 : 0) : chain + 1);
+                if (term) {
+                    if (count >= 4) { fill = count >> 2; fillv = (uint32_t)v * 0x01010101u; }
+                    else {
+                        acc |= ((count == 2 ? 0x0101u : 1u) * (uint32_t)v) << (8 * na);
+                        na += count;
+                        if (na == 4) { tile[q * 64 + ((lane + lds_rot(q)) & 63)] = acc; ++q; acc = 0; na = 0; }
+                    }
+                    uint32_t np = p + 1u;
+                    np >>= (__ffs((int)np) - 1);
+                    p = np;
+                    if (np == 1u) { p = 0x80000000u; done = fill == 0; }   // parked: no further tokens are mine
                 }
-                acc |= (uint32_t)v << (8 * na); ++na;
-                terminal = true;
             }
-            if (na == 4) { tile[q * 64 + ((lane + lds_rot(q)) & 63)] = acc; ++q; acc = 0; na = 0; }
-            if (terminal) {
-                while (j > 0 && (path & 1u)) { path >>= 1; --j; }
-                if (j == 0) break;
-                path |= 1u;
-            } else { stk[j * 64 + lane] = (uint8_t)v; ++j; path <<= 1; }
+            if (nb <= 32) { buf |= (unsigned long long)wn << nb; nb += 32; ++wi; }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my LDS writes have landed
