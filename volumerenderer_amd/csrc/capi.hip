@@ -159,7 +159,7 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     b.heapStride = (int64_t)1 << (b.D + 1);
     b.leafStride = (int64_t)1 << b.D;
     const int64_t numMax = b.heapStride - 1 + VR_CHAIN_LEVELS * b.leafStride; // numMaxNodes R.cpp:35
-    b.treeCap = ((numMax + 15) / 16 + 2) * 4;
+    b.treeCap = ((numMax + 15) / 16 + 2) * 4 + 256;   // slack: the decoder stages whole words past a run's end
     b.nIdx = (int64_t)1 << b.Ds;
     vr_status rc = alloc_stream2(b, b.mid, false);
     if (rc == VR_OK) {

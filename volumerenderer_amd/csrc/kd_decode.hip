@@ -119,15 +119,23 @@ k_decode_lane(DecodeArgs a)
     }
 }
 
-// ---- v2: tile decode --------------------------------------------------------------
-// One lane decodes one depth-(D-6) subtree = a 4x4x4 voxel block (64 leaves, up to
-// ~600 tokens).  A wave takes 32x2x1 such blocks = a 128x8x4 voxel tile whose rows are
-// whole 128-byte lines of the output volume.  Lanes emit their leaves in stream (Morton)
-// order, four per dword, into an LDS tile laid out [dword q][lane] (bank = lane, so
-// the divergent walk writes conflict-free); the wave then gathers 16-byte row pieces
-// from it and stores 8 full lines per instruction.  Requirements: the six deepest
-// split levels cycle through x,y,z twice (any order) and X>=128, Y>=8, Z>=4;
-// everything else takes k_decode_lane.
+// ---- tile decode --------------------------------------------------------------------
+// One lane decodes one depth-(D-6) subtree = a 4x4x4 voxel block (64 leaves, up to 639
+// tokens).  A wave takes 32x2x1 such blocks = a 128x8x4 voxel tile whose rows are whole
+// 128-byte lines of the output volume.
+//   stage   every lane copies the next DEC_SW words of ITS token run into LDS
+//           ([word][lane], bank = lane), so the walk can look 16 tokens ahead at any
+//           bit position with one ds_read2st64_b32 + v_alignbit;
+//   walk    a uniform loop, one action per lane and iteration: a tree token, a
+//           grown-branch step, or 4 voxels of a pruned node's fill.  A branch step skips
+//           a run of "keep" codes with one ctz and swallows a following terminator, and
+//           a leaf swallows an immediate terminator, so a voxel costs ~3 iterations
+//           instead of one per token.  Leaves are emitted in stream (Morton) order as
+//           bytes into an LDS tile [leaf][lane];
+//   gather  the wave re-reads the tile as 16-byte row pieces and stores 8 full 128-byte
+//           lines per instruction.
+// Requirements: the six deepest split levels cycle through x,y,z twice (any order) and
+// X>=128, Y>=8, Z>=4; everything else takes k_decode_lane.
 struct TileArgs {
     const uint8_t *tree;
     int64_t treeCap;
@@ -143,30 +151,39 @@ struct TileArgs {
 };
 
 #define DEC_WAVES 4
+#define DEC_DUMMY_ROW 64
+#define DEC_SW 16            // staged words per lane (usable lookahead: DEC_SW-2 words per stage)
 
-// rotation of the lane index inside dword row q of the LDS tile (see the gather stage): (q0+q1+q2+2*q3)&3, as a packed table
-__device__ __forceinline__ int lds_rot(int q) { return (int)((0x433EE994u >> (2 * q)) & 3u); }
+__device__ __forceinline__ int clamp_add(int pv, int tok, int dist)
+{   // decoder step R.cpp:783-787 / 814-818, branch-free
+    const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+    int nv = pv + delta;
+    return nv < 0 ? 0 : (nv > 255 ? 255 : nv);
+}
 
 __global__ void __launch_bounds__(64 * DEC_WAVES)
 k_decode_tile(TileArgs a)
 {
-    __shared__ uint32_t tileS[DEC_WAVES][16 * 64];
-    __shared__ uint8_t stkS[DEC_WAVES][8 * 64];
+    __shared__ uint8_t tileS[DEC_WAVES][65 * 64];      // [leaf][lane]; row 64 = scratch for predicated-off writes
+    __shared__ uint32_t strS[DEC_WAVES][DEC_SW * 64];   // [word][lane]
+    __shared__ uint8_t stkS[DEC_WAVES][8 * 64];         // [level][lane]
     __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * DEC_WAVES + wave;
-    const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
-    uint32_t *tile = tileS[wave];
+    uint8_t *tile = tileS[wave];
+    uint32_t *str = strS[wave];
     uint8_t *stk = stkS[wave];
     const bool tileValid = tileId < a.tilesX * a.tilesY * a.tilesZ;
     if (threadIdx.x < 16) {
         const uint8_t *dmap = a.ctrls[brick].distanceMap;
         const int t = threadIdx.x;
-        dmS[t] = t == 0 ? 0 : (t < 8 ? dmap[a.Ds + (t < 7 ? t : 0)] : dmap[a.D + (t - 8)]);   // [0] = 0: the subtree root keeps the index value
+        // [0] = 0: the subtree root keeps the value stored in the index
+        dmS[t] = t == 0 ? 0 : (t < 8 ? dmap[a.Ds + (t < 7 ? t : 0)] : dmap[a.D + (t - 8)]);
     }
     __syncthreads();
     if (!tileValid) return;
+    const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
 
     // ---- which subtree is mine
     int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};   // subtree coords (units of 4 voxels)
@@ -175,79 +192,88 @@ k_decode_tile(TileArgs a)
     const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
     const int val0 = a.idxVal[(int64_t)brick * a.nIdx + s];
 
-    // ---- walk my token run, leaves out in Morton order.
-    // One action per iteration and lane (consume one token, or write one dword of a
-    // pruned node's fill), so the wave runs a short uniform loop body instead of nested
-    // divergent loops.  Tokens come from a 64-bit buffer topped up with one 32-bit word
-    // every 16 iterations: a lane consumes at most 16 tokens per block, so >= 32 valid
-    // bits at block start can never underflow, and the word loaded at block start is only
-    // merged at block end -- its global-memory latency hides behind the 16 iterations.
-    if (off == VR_IDX_DEAD) {
-        const uint32_t vv = (uint32_t)val0 * 0x01010101u;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tile[q * 64 + ((lane + lds_rot(q)) & 63)] = vv;
-    }
     {
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
-        bool done = off == VR_IDX_DEAD;
-        const uint32_t o0 = done ? 0u : off;
-        uint32_t wi = o0 >> 4;
-        const int sh0 = (int)(o0 & 15u) * 2;
-        unsigned long long buf = ((unsigned long long)W[wi] | ((unsigned long long)W[wi + 1] << 32)) >> sh0;
-        int nb = 64 - sh0;
-        wi += 2;
+        const bool dead = off == VR_IDX_DEAD;
+        bool done = false;
+        uint32_t wbase = dead ? 0u : (off >> 4);
+        uint32_t bitpos = dead ? 0u : (off & 15u) * 2u;     // relative to the staged window
         uint32_t p = 1;                 // path with a leading sentinel bit: depth = bitlen(p) - 1
         int chain = 0;                  // 0: tree token expected, 1..7: next grown-branch step
         int v = val0;
-        int fill = 0, q = 0, na = 0;
-        uint32_t fillv = 0, acc = 0;
+        int fill = dead ? 64 : 0;       // voxels of a pruned node still to write
+        int leaf = 0;                   // next leaf (Morton rank) to emit
+        if (dead) p = 0x80000000u;
         // value stack rows 0..5 = pushed ancestors, row 6 = scratch for predicated-off pushes,
-        // row 7 = root's "parent" (the index value itself; dmS[0] = 0 leaves it unchanged)
+        // row 7 = the root's "parent" (the index value itself; dmS[0] = 0 leaves it unchanged)
         stk[7 * 64 + lane] = (uint8_t)val0;
         while (__ballot(!done) != 0ull) {
-            const uint32_t wn = W[wi];  // consumed (maybe) at the end of this block
-#pragma unroll 1
-            for (int it = 0; it < 16; ++it) {
-                if (done) continue;
-                if (fill > 0) {
-                    tile[q * 64 + ((lane + lds_rot(q)) & 63)] = fillv;
-                    ++q;
-                    if (--fill == 0 && p == 0x80000000u) done = true;
-                    continue;
+            // ---- stage the next DEC_SW words of my run
+            wbase += bitpos >> 5;
+            bitpos &= 31u;
+#pragma unroll
+            for (int k = 0; k < DEC_SW; ++k) str[k * 64 + lane] = W[wbase + k];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            // ---- walk while somebody can still look ahead.  The body is branch-free per lane
+            // (selects + LDS writes steered to a scratch row): divergent branches here cost more
+            // scalar exec-mask instructions than the vector work they skip.
+            while (true) {
+                const bool act = !done && (bitpos >> 5) < DEC_SW - 2;
+                if (__ballot(act) == 0ull) break;
+                const bool filling = act && fill > 0;
+                if (__ballot(filling) != 0ull) {            // wave-uniform: skipped when nobody fills
+                    const int n4 = filling ? (fill < 4 ? fill : 4) : 0;
+                    uint8_t *t4 = tile + lane;
+                    const uint8_t fv = (uint8_t)v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t4[(i < n4 ? leaf + i : DEC_DUMMY_ROW) * 64] = fv;
+                    leaf += n4; fill -= n4;
+                    done = done || (filling && fill == 0 && p == 0x80000000u);
                 }
-                // ---- one token, straight-line (selects, no branches)
-                const int tok = (int)(buf & 3ull);
-                buf >>= 2; nb -= 2;
-                const int j = 31 - __clz((int)p);
+                const bool tk = act && !filling;            // this lane consumes tokens now
+                const uint32_t k = bitpos >> 5;
+                const uint32_t w0 = str[k * 64 + lane], w1 = str[(k + 1) * 64 + lane];
+                const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);   // 16 tokens ahead
                 const bool tree = chain == 0;
-                const int sv = stk[(tree ? ((j + 7) & 7) : 7) * 64 + lane];
-                const int dist = dmS[tree ? j : 8 + chain];
-                const int pv = tree ? sv : v;
-                const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
-                int nv = pv + delta;
-                nv = nv < 0 ? 0 : (nv > 255 ? 255 : nv);       // decoder step R.cpp:783-787
-                v = nv;
-                const bool is3 = tok == 3;
-                const bool term = is3 || chain == VR_CHAIN_LEVELS;
+                // tree token at depth j
+                const int j = (31 - __clz((int)p)) & 7;
+                // grown branch: steps chain..7 of the same voxel (distances 64..1): skip "keep" codes
+                const int rem = 8 - chain;
+                const int z = (__ffs((int)(x | (1u << (2 * rem)))) - 1) >> 1;
+                const int c2 = chain + z;                       // step of the first non-keep token
+                const bool exhausted = !tree && z >= rem;       // only keeps up to depth D+7
+                const int tok = (int)((tree ? x : (x >> (2 * z))) & 3u);
+                const int dist = dmS[tree ? j : 8 + (c2 < 7 ? c2 : 7)];
+                const int sv = stk[((j + 7) & 7) * 64 + lane];
+                const int nv = clamp_add(tree ? sv : v, exhausted ? 0 : tok, dist);
+                const bool is3 = tok == 3 && !exhausted;
                 const bool desc = tree && !is3 && j < 6;
-                stk[(desc ? j : 6) * 64 + lane] = (uint8_t)v;
-                const int count = tree ? (64 >> j) : 1;
-                p = desc ? (p << 1) : p;
-                chain = term ? 0 : (tree ? (j == 6 ? 1 : 0) : chain + 1);
-                if (term) {
-                    if (count >= 4) { fill = count >> 2; fillv = (uint32_t)v * 0x01010101u; }
-                    else {
-                        acc |= ((count == 2 ? 0x0101u : 1u) * (uint32_t)v) << (8 * na);
-                        na += count;
-                        if (na == 4) { tile[q * 64 + ((lane + lds_rot(q)) & 63)] = acc; ++q; acc = 0; na = 0; }
-                    }
-                    uint32_t np = p + 1u;
-                    np >>= (__ffs((int)np) - 1);
-                    p = np;
-                    if (np == 1u) { p = 0x80000000u; done = fill == 0; }   // parked: no further tokens are mine
-                }
+                const bool lf = tree && !is3 && j == 6;
+                const int sh = tree ? 2 : 2 * z + 2;
+                const bool nxt3 = ((x >> sh) & 3u) == 3u;       // a terminator follows: swallow it
+                const bool last = !tree && c2 >= VR_CHAIN_LEVELS;
+                const bool term = tree ? (is3 || (lf && nxt3)) : (exhausted || is3 || last || nxt3);
+                const int used = tree ? ((lf && nxt3) ? 4 : 2)
+                                      : (exhausted ? 2 * rem : 2 * z + 2 + ((!is3 && !last && nxt3) ? 2 : 0));
+                const int nchain = tree ? ((lf && !nxt3) ? 1 : 0) : (term ? 0 : c2 + 1);
+                const int count = (tree && is3) ? (64 >> j) : 1;
+                // commit
+                v = tk ? nv : v;
+                stk[((tk && desc) ? j : 6) * 64 + lane] = (uint8_t)nv;
+                p = (tk && desc) ? (p << 1) : p;
+                chain = tk ? nchain : chain;
+                bitpos += tk ? (uint32_t)used : 0u;
+                const bool t = tk && term;
+                const bool single = t && count == 1;
+                tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)nv;
+                leaf += single ? 1 : 0;
+                fill = (t && count > 1) ? count : fill;
+                uint32_t np = p + 1u;
+                np >>= (__ffs((int)np) - 1);
+                const bool parked = t && np == 1u;              // no further tokens are mine
+                p = t ? (parked ? 0x80000000u : np) : p;
+                done = done || (parked && fill == 0);
             }
-            if (nb <= 32) { buf |= (unsigned long long)wn << nb; nb += 32; ++wi; }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my LDS writes have landed
@@ -257,33 +283,20 @@ k_decode_tile(TileArgs a)
     const int jx = a.jx, jy = a.jy, jz = a.jz;
     const int c = lane & 7;
     uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16;
+    const int r1 = 1 << jx, r2 = 8 << jx;            // Morton rank steps of dx bit 0 / bit 1
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int R = st * 8 + (lane >> 3);
         const int y = R & 7, z = R >> 3;
         const int dy = y & 3, dz = z & 3;
         const int rb = ((dy & 1) << jy) | ((dy >> 1) << (3 + jy)) | ((dz & 1) << jz) | ((dz >> 1) << (3 + jz));
-        const int q0 = rb >> 2, b0 = rb & 3;
-        const int lsBase = 4 * c + 32 * (y >> 2);
+        const uint8_t *src = tile + rb * 64 + 4 * c + 32 * (y >> 2);
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int Ls = lsBase + k;
-            if (jx == 0) {          // dx0 -> byte +1, dx1 -> dword +2
-                uint32_t A = tile[q0 * 64 + ((Ls + lds_rot(q0)) & 63)], B = tile[(q0 + 2) * 64 + ((Ls + lds_rot(q0 + 2)) & 63)];
-                uint32_t lo = (A >> (8 * b0)) & 0xFFFFu, hi = (B >> (8 * b0)) & 0xFFFFu;
-                o[k] = lo | (hi << 16);
-            } else if (jx == 1) {   // dx0 -> byte +2, dx1 -> dword +4
-                uint32_t A = tile[q0 * 64 + ((Ls + lds_rot(q0)) & 63)], B = tile[(q0 + 4) * 64 + ((Ls + lds_rot(q0 + 4)) & 63)];
-                uint32_t a0 = (A >> (8 * b0)) & 0xFFu, a1 = (A >> (8 * b0 + 16)) & 0xFFu;
-                uint32_t c0 = (B >> (8 * b0)) & 0xFFu, c1 = (B >> (8 * b0 + 16)) & 0xFFu;
-                o[k] = a0 | (a1 << 8) | (c0 << 16) | (c1 << 24);
-            } else {                // dx0 -> dword +1, dx1 -> dword +8
-                uint32_t A = tile[q0 * 64 + ((Ls + lds_rot(q0)) & 63)], B = tile[(q0 + 1) * 64 + ((Ls + lds_rot(q0 + 1)) & 63)];
-                uint32_t C2 = tile[(q0 + 8) * 64 + ((Ls + lds_rot(q0 + 8)) & 63)], D2 = tile[(q0 + 9) * 64 + ((Ls + lds_rot(q0 + 9)) & 63)];
-                o[k] = ((A >> (8 * b0)) & 0xFFu) | (((B >> (8 * b0)) & 0xFFu) << 8) | (((C2 >> (8 * b0)) & 0xFFu) << 16) |
-                       (((D2 >> (8 * b0)) & 0xFFu) << 24);
-            }
+            const uint8_t *sk = src + k;
+            o[k] = (uint32_t)sk[0] | ((uint32_t)sk[r1 * 64] << 8) | ((uint32_t)sk[r2 * 64] << 16) |
+                   ((uint32_t)sk[(r1 + r2) * 64] << 24);
         }
         const int64_t gy = (int64_t)ty * 8 + y, gz = (int64_t)tz * 4 + z;
         *(uint4 *)(O + (int64_t)a.g.X * (gy + (int64_t)a.g.Y * gz)) = make_uint4(o[0], o[1], o[2], o[3]);
