@@ -81,6 +81,82 @@ k_pyramid(Geom g, int dLeaf, int L, const uint8_t *__restrict__ vox, const uint8
     }
 }
 
+// Bottom 12 levels in one block: the 4096 leaves under one depth-(D-12) node form a
+// 2^ax x 2^ay x 2^az box (ax+ay+az = 12).  With ax >= 4 every thread fetches one aligned
+// 16-byte x-run of voxels (coalesced), scatters it to Morton order in LDS, and the block
+// reduces min/max twelve times there; leaves and the dense levels leave as 16/8/4-byte
+// stores.  Replaces the per-voxel gather of k_pyramid<true>.
+struct Pyr12Geom { int ax, ay, az; uint16_t sx[16]; };   // sx[i]: Morton rank bits of x = i (low 4 x bits)
+
+__global__ void __launch_bounds__(256)
+k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__restrict__ temp, int64_t heapStride,
+            uint8_t *__restrict__ tempRange, uint8_t *__restrict__ outMin, uint8_t *__restrict__ outMax,
+            int64_t outStride)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smn[2][4096], smx[2][4096];
+    const int brick = blockIdx.y, D = g.D;
+    const uint32_t base = blockIdx.x << 12;
+    uint8_t *T = temp + (int64_t)brick * heapStride;
+    uint8_t *TR = tempRange ? tempRange + (int64_t)brick * heapStride : nullptr;
+    int bx, by, bz;
+    rank_to_xyz(g, base, bx, by, bz);
+    const int t = threadIdx.x;
+    const int nxs = 1 << (pg.ax - 4);
+    const int xs = t & (nxs - 1), y = (t >> (pg.ax - 4)) & ((1 << pg.ay) - 1), z = t >> (pg.ax - 4 + pg.ay);
+    // Morton rank of (xs*16, y, z) inside the box: walk the 12 deepest split levels
+    uint32_t r0 = 0;
+    {
+        const int cx = xs * 16, c[3] = {cx, y, z};
+        for (int q = 0; q < 12; ++q) {
+            const int dd = D - 12 + q;
+            r0 = (r0 << 1) | ((uint32_t)(c[g.axis[dd]] >> g.bit[dd]) & 1u);
+        }
+    }
+    const uint4 v4 = *(const uint4 *)(vox + (int64_t)brick * g.voxels + (bx + xs * 16) +
+                                      (int64_t)g.X * ((by + y) + (int64_t)g.Y * (bz + z)));
+    const uint32_t vw[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint8_t v = (uint8_t)(vw[i >> 2] >> ((i & 3) * 8));
+        const uint32_t r = r0 | pg.sx[i];
+        smn[0][r] = v;
+        smx[0][r] = v;
+    }
+    __syncthreads();
+    // leaves: 16 per thread, Morton order is the heap's leaf order
+    *(uint4 *)(T + ((int64_t)1 << D) + base + t * 16) = *(const uint4 *)(&smn[0][t * 16]);   // (v+v)/2 = v
+    if (TR) *(uint4 *)(TR + ((int64_t)1 << D) + base + t * 16) = make_uint4(0, 0, 0, 0);
+    for (int l = 1; l <= 12; ++l) {
+        const int m = 4096 >> l;
+        const int src = (l - 1) & 1, dst = l & 1;
+        const int npt = m >= 256 ? m / 256 : 1;        // 8, 4, 2, 1, 1, ...
+        const int64_t lvl = ((int64_t)1 << (D - l)) + (base >> l);
+        if (t * npt < m) {
+            unsigned long long packM = 0, packR = 0;
+            for (int k = 0; k < npt; ++k) {
+                const int i = t * npt + k;
+                const uint8_t a = smn[src][2 * i], b = smn[src][2 * i + 1];
+                const uint8_t c = smx[src][2 * i], d2 = smx[src][2 * i + 1];
+                const uint8_t mn = a < b ? a : b, mx = c > d2 ? c : d2;
+                smn[dst][i] = mn;
+                smx[dst][i] = mx;
+                packM |= (unsigned long long)(((int)mx + (int)mn) >> 1) << (8 * k);   // R.cpp:198
+                packR |= (unsigned long long)(((int)mx - (int)mn) >> 1) << (8 * k);   // M.cpp:235
+            }
+            uint8_t *dstp = T + lvl + t * npt;
+            if (npt == 8) { *(unsigned long long *)dstp = packM; if (TR) *(unsigned long long *)(TR + lvl + t * 8) = packR; }
+            else if (npt == 4) { *(uint32_t *)dstp = (uint32_t)packM; if (TR) *(uint32_t *)(TR + lvl + t * 4) = (uint32_t)packR; }
+            else if (npt == 2) { *(uint16_t *)dstp = (uint16_t)packM; if (TR) *(uint16_t *)(TR + lvl + t * 2) = (uint16_t)packR; }
+            else { *dstp = (uint8_t)packM; if (TR) TR[lvl + t] = (uint8_t)packR; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        outMin[(int64_t)brick * outStride + blockIdx.x] = smn[0][0];
+        outMax[(int64_t)brick * outStride + blockIdx.x] = smx[0][0];
+    }
+}
+
 // --------------------------------------------------------------- compress ----
 struct ReconBufs { uint8_t *b[3]; };
 
@@ -380,6 +456,63 @@ k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict
         blockErr[(int64_t)brick * nErrBlk + blockIdx.x] = e0;
         if (em) atomicAdd(&c.errMinus, em);
         if (ep) atomicAdd(&c.errPlus, ep);
+    }
+}
+
+// Vector form of k_fill for levels with >= 4096 nodes: 16 consecutive nodes per thread
+// (one 16-byte load of truths, one 8-byte load of parents, 16-byte stores of codes and
+// reconstructions); a wave covers exactly one 1024-node partial-sum block of k_control.
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_fill16(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
+         ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+{
+    __shared__ unsigned long long shm[4], shp[4];
+    const int brick = blockIdx.y;
+    Ctrl &c = ctrls[brick];
+    if (!c.fillThisEpoch) return;
+    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    uint8_t *Cd = codes + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
+    uint8_t *R = rb.b[phys_buf(c, c.cur)] + (int64_t)brick * leafStride;
+    const int dist = (int)(uint8_t)c.currentDistance;
+    const int distM = (int)(uint8_t)fmax(0.0, c.currentDistance - 1.0);   // R.cpp:334
+    const int distP = (int)(uint8_t)fmin(255.0, c.currentDistance + 1.0);
+    const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
+    const uint4 tv = *(const uint4 *)(T + i0);
+    const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
+    uint32_t cw[4] = {0, 0, 0, 0}, rw[4] = {0, 0, 0, 0};
+    uint32_t e0 = 0, em = 0, ep = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = (tw[k >> 2] >> ((k & 3) * 8)) & 255, p = (pw[k >> 3] >> (((k >> 1) & 3) * 8)) & 255;
+        const Enc e = encode_node(t, p, dist);
+        cw[k >> 2] |= (uint32_t)e.code << ((k & 3) * 8);
+        rw[k >> 2] |= (uint32_t)e.recon << ((k & 3) * 8);
+        e0 += (uint32_t)(e.err * e.err);
+        const int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
+        em += (uint32_t)(a * a);
+        ep += (uint32_t)(b * b);
+    }
+    *(uint4 *)(Cd + i0) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+    const unsigned long long s0 = wave_sum_u64(e0), sm = wave_sum_u64(em), sp = wave_sum_u64(ep);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        blockErr[(int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = s0;   // 1024 nodes per wave
+        shm[w] = sm; shp[w] = sp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long tm = shm[0] + shm[1] + shm[2] + shm[3], tp = shp[0] + shp[1] + shp[2] + shp[3];
+        if (tm) atomicAdd(&c.errMinus, tm);
+        if (tp) atomicAdd(&c.errPlus, tp);
     }
 }
 
@@ -871,8 +1004,12 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
             }
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
-            hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
-                               s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+            if (n >= 4096)
+                hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, s.ctrl, s.temp,
+                                   s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+            else
+                hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
+                                   s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
             hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, guarded, s.ctrl, s.temp,
                                bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
         }
@@ -895,16 +1032,43 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     const int D = bs->D, B = bs->B;
     const bool mr = bs->variant == 2;
     hipEventRecord(bs->ev[0], st);
-    // ---- BUILD: pyramid in rounds of <= 10 levels
+    // ---- BUILD: pyramid.  Bottom 12 levels by k_pyramid12 when x-runs of 16 voxels exist,
+    // the rest (and small / thin bricks) in rounds of <= 10 levels.
     {
         int dLeaf = D, round = 0;
         const uint8_t *inMin = nullptr, *inMax = nullptr;
         int64_t inStride = 0;
-        while (true) {
+        const int64_t oStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
+        Pyr12Geom pg{};
+        bool use12 = D >= 12;
+        if (use12) {
+            for (int q = 0; q < 12; ++q) {
+                const int ax = bs->g.axis[D - 12 + q];
+                if (ax == 0) pg.ax++; else if (ax == 1) pg.ay++; else pg.az++;
+            }
+            use12 = pg.ax >= 4;
+            for (int i = 0; i < 16 && use12; ++i) {
+                uint32_t r = 0;
+                for (int q = 0; q < 12; ++q) {
+                    const int dd = D - 12 + q;
+                    const int cbit = bs->g.axis[dd] == 0 ? (i >> bs->g.bit[dd]) & 1 : 0;
+                    r = (r << 1) | (uint32_t)(bs->g.bit[dd] < 4 ? cbit : 0);
+                }
+                pg.sx[i] = (uint16_t)r;
+            }
+        }
+        if (use12) {
+            hipLaunchKernelGGL(k_pyramid12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, bs->g, pg, vox,
+                               bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr, bs->mmMin[0], bs->mmMax[0],
+                               oStride);
+            dLeaf = D - 12;
+            inMin = bs->mmMin[0]; inMax = bs->mmMax[0]; inStride = oStride;
+            round = 1;
+        }
+        while (dLeaf > 0 || round == 0) {
             int L = dLeaf < 10 ? dLeaf : 10;
             int64_t nblk = (int64_t)1 << (dLeaf - L);
             uint8_t *oMin = bs->mmMin[round & 1], *oMax = bs->mmMax[round & 1];
-            int64_t oStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
             if (round == 0)
                 hipLaunchKernelGGL(k_pyramid<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, bs->g, dLeaf, L, vox,
                                    inMin, inMax, inStride, bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr,
