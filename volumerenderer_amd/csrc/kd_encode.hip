@@ -963,6 +963,146 @@ k_emit_write(EmitArgs a)
     }
 }
 
+// ---- emit, 4 leaf ranks per thread (VolumeKdtree streams with D >= 12) -----------------
+// Thread t of a block owns ranks r0..r0+3 (r0 = 4t): the spine above the quad (first leaf
+// r0), the depth-(D-2) node, both depth-(D-1) nodes and the four leaves with their grown
+// branches -- at most D+1+32 tokens, assembled in a 128-bit register string.  Leaf arrays
+// are read as dwords; one block = 1024 ranks.
+#define EMIT4_RANKS 1024
+#define EMIT4_LDS_WORDS 640     // >= (1024*8 + 1023 + 28 + 15) / 16
+
+struct Str128 { unsigned long long lo, hi; int n; };
+__device__ __forceinline__ void str_put(Str128 &s, uint32_t bits, int ntok)
+{
+    const int sh = 2 * s.n;
+    if (sh < 64) {
+        s.lo |= (unsigned long long)bits << sh;
+        if (sh > 32) s.hi |= (unsigned long long)bits >> (64 - sh);
+    } else s.hi |= (unsigned long long)bits << (sh - 64);
+    s.n += ntok;
+}
+
+struct Quad { Str128 s; int preDs, aliveAtDs, maxErr; uint32_t l1; };
+
+__device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ Tb,
+                                   const uint8_t *__restrict__ Rl, int D, int maxDepth, int tol, const uint8_t *dmap,
+                                   int Ds, uint32_t r0)
+{
+    Quad Q;
+    Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0; Q.maxErr = 0; Q.l1 = 0;
+    const int jmin = r0 ? D - (__ffs((int)r0) - 1) : 0;          // <= D-2
+    bool alive = true;
+    if (jmin > 0) alive = Cb[((int64_t)1 << (jmin - 1)) + (r0 >> (D - jmin + 1))] != 3;
+    for (int j = jmin; alive && j <= D - 2; ++j) {                 // spine down to the quad's depth-(D-2) node
+        if (j == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
+        const int code = Cb[((int64_t)1 << j) + (r0 >> (D - j))];
+        str_put(Q.s, (uint32_t)code, 1);
+        if (code == 3) alive = false;
+    }
+    if (!alive) return Q;
+    const uint32_t pair = *(const uint16_t *)(Cb + ((int64_t)1 << (D - 1)) + (r0 >> 1));
+    const uint32_t cl = *(const uint32_t *)(Cb + ((int64_t)1 << D) + r0);
+    const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
+    const uint32_t rl = *(const uint32_t *)(Rl + r0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pc = (pair >> (8 * h)) & 255;
+        if (h == 0 && D - 1 == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
+        str_put(Q.s, (uint32_t)pc, 1);
+        if (pc == 3) continue;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = 2 * h + e;
+            if (k == 0 && D == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
+            const int code = (cl >> (8 * k)) & 255, t = (tl >> (8 * k)) & 255;
+            int rec = (rl >> (8 * k)) & 255;
+            uint32_t bits = (uint32_t)code;
+            int nt = 1;
+            if (code != 3) {
+                int depth = D;
+                while (depth < maxDepth) {                          // grown branch, R.cpp:655-704
+                    const int err = rec > t ? rec - t : t - rec;
+                    if (err > tol) {
+                        ++depth;
+                        const Enc en = encode_node(t, rec, dmap[depth]);
+                        rec = en.recon;
+                        bits |= (uint32_t)en.code << (2 * nt);
+                        ++nt;
+                    } else { bits |= 3u << (2 * nt); ++nt; break; }
+                }
+            }
+            str_put(Q.s, bits, nt);
+            const int fe = rec > t ? rec - t : t - rec;
+            Q.maxErr = fe > Q.maxErr ? fe : Q.maxErr;
+            Q.l1 += (uint32_t)fe;
+        }
+    }
+    return Q;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_emit4(EmitArgs a)
+{
+    __shared__ uint32_t shw[4];
+    __shared__ uint32_t W[WRITE ? EMIT4_LDS_WORDS : 1];
+    __shared__ unsigned long long shl1[4];
+    const int brick = blockIdx.y;
+    Ctrl &c = a.ctrls[brick];
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
+    const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
+    const uint32_t r0 = blockIdx.x * EMIT4_RANKS + threadIdx.x * 4;
+    if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
+    const Quad Q = quad_tokens(Cb, Tb, Rl, a.D, a.maxDepth, a.tol, c.distanceMap, a.Ds, r0);
+    uint32_t tot;
+    const uint32_t lo = block_excl_scan_u32((uint32_t)Q.s.n, shw, tot);
+    if (!WRITE) {
+        if (threadIdx.x == 0) a.blockTot[(int64_t)brick * a.nEmitBlk + blockIdx.x] = tot;
+        return;
+    }
+    const uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blockIdx.x];
+    const uint32_t phase = g0 & 15u;
+    if (Q.s.n) {
+        const uint32_t pos = phase + lo;
+        const int sh = (int)(pos & 15u) * 2;
+        uint32_t w = pos >> 4;
+        // 128-bit string shifted into up to five words
+        const unsigned long long v0 = Q.s.lo << sh;
+        const unsigned long long v1 = (Q.s.hi << sh) | (sh ? (Q.s.lo >> (64 - sh)) : 0ull);
+        const uint32_t v2 = sh ? (uint32_t)(Q.s.hi >> (64 - sh)) : 0u;
+        const int nbits = sh + 2 * Q.s.n;
+        atomicOr(&W[w], (uint32_t)v0);
+        if (nbits > 32) atomicOr(&W[w + 1], (uint32_t)(v0 >> 32));
+        if (nbits > 64) atomicOr(&W[w + 2], (uint32_t)v1);
+        if (nbits > 96) atomicOr(&W[w + 3], (uint32_t)(v1 >> 32));
+        if (nbits > 128) atomicOr(&W[w + 4], v2);
+    }
+    if ((r0 & ((1u << a.K) - 1u)) == 0) {     // decode side-car index entry (K >= 2)
+        const uint32_t sidx = r0 >> a.K;
+        int val = c.distanceMap[0];
+        for (int j = 1; j <= a.Ds; ++j) val = apply_code(val, Cb[((int64_t)1 << j) + (sidx >> (a.Ds - j))], c.distanceMap[j]);
+        a.idxOff[(int64_t)brick * a.nIdx + sidx] = Q.aliveAtDs ? g0 + lo + (uint32_t)Q.preDs : VR_IDX_DEAD;
+        a.idxVal[(int64_t)brick * a.nIdx + sidx] = (uint8_t)val;
+    }
+    int fe = Q.maxErr;
+    unsigned long long l1 = Q.l1;
+    for (int q = 32; q > 0; q >>= 1) { int u = __shfl_xor(fe, q); fe = u > fe ? u : fe; l1 += __shfl_xor(l1, q); }
+    if ((threadIdx.x & 63) == 0) {
+        if (fe > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, fe);
+        shl1[threadIdx.x >> 6] = l1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.blockL1[(int64_t)brick * a.nEmitBlk + blockIdx.x] = shl1[0] + shl1[1] + shl1[2] + shl1[3];
+    if (tot == 0) return;
+    uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
+    const uint32_t nw = ((phase + tot - 1) >> 4) + 1;
+    for (uint32_t i = threadIdx.x; i < nw; i += 256) {
+        if (i == 0 || i == nw - 1) { if (W[i]) atomicOr(&G[i], W[i]); }
+        else G[i] = W[i];
+    }
+}
+
 __global__ void __launch_bounds__(1024)
 k_emit_stats(EmitArgs a, int64_t nblk)
 {
@@ -1112,11 +1252,14 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.blockL1 = bs->blockL1;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
-    const int64_t nblk = cdiv((int64_t)1 << D, EMIT_RANKS_PER_BLOCK);
-    hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
+    const bool quad = !mr && D >= 12 && bs->K >= 2;
+    const int64_t nblk = cdiv((int64_t)1 << D, quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK);
+    if (quad) hipLaunchKernelGGL(k_emit4<false>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-    hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
+    if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, nblk);
     hipEventRecord(bs->ev[4], st);
     return launch_status("encode");
