@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- kd-tree compress+decode throughput (Mvoxels/s) of the HIP hot path, with
-the decode kernel's HBM roofline and the CPU oracle timed beside it.
+the decode kernel's HBM roofline, the 1080p ray-cast rate and the CPU oracle beside it.
 
   python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; bricks are sharded across
-ranks with no data-path collective (weak scaling: every rank encodes+decodes the same
-number of bricks).  A "step" = one build() + one levelCut() of the rank's brick batch.
+
+Workload (BASELINE.json metric): one 2048x2048x1920 uint8 volume = the reference's 8x8x15
+grid of 256x256x128 bricks (main.cpp:78-79), one kd-tree per brick, all 960 trees built and
+decoded by one batched launch sequence.  A "step" = build() + levelCut() of the whole
+volume (+ one 1080p ray-cast frame of the decoded volume, timed separately).
+N > 1 (torch.distributed.run, one rank per GPU): bricks / timesteps shard with no data-path
+collective -- every rank encodes+decodes its own timestep of the volume (weak scaling).
 """
 import argparse
-import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -23,7 +27,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def make_bricks(kind, n_bricks, dims, seed=12345):
-    """Synthetic uint8 bricks.  dims = (X, Y, Z); returns [B][Z][Y][X]."""
+    """Small host-side synthetic bricks (tests, cpu baseline).  dims = (X, Y, Z); [B][Z][Y][X]."""
     X, Y, Z = dims
     out = np.empty((n_bricks, Z, Y, X), np.uint8)
     z, y, x = np.meshgrid(np.arange(Z, dtype=np.float32), np.arange(Y, dtype=np.float32),
@@ -34,7 +38,6 @@ def make_bricks(kind, n_bricks, dims, seed=12345):
             r = np.sqrt((x - X / 2) ** 2 + (y - Y / 2) ** 2 + (z - Z / 2) ** 2) / (min(X, Y, Z) / 2)
             v = np.floor(255.0 * np.maximum(0.0, 1.0 - r)) + rng.integers(0, 8, (Z, Y, X))
         elif kind == "rm_like":
-            # two-fluid interface with a perturbed mixing layer; noise only inside the layer
             h = Z / 2 + (Z / 16.0) * (np.sin(x * (2 * np.pi * 3 / X) + b) + np.cos(y * (2 * np.pi * 5 / Y) - b)
                                        + 0.5 * np.sin((x + y) * (2 * np.pi * 7 / X)))
             d = (z - h) / 6.0
@@ -48,18 +51,63 @@ def make_bricks(kind, n_bricks, dims, seed=12345):
     return out
 
 
+def make_volume_gpu(torch, gdims, bdims, seed, kind="rm_volume"):
+    """Richtmyer-Meshkov-like two-fluid volume generated on the GPU, returned brick by brick
+    ([B][Z][Y][X] uint8, brick b at grid (i,j,k) = fillVolumeBrickMap order, main.cpp:599-619).
+
+    heavy fluid below a perturbed interface, light above, a mixing layer ~ Z/6 thick with
+    multi-scale perturbations and 2-bit sensor noise inside the layer; pure-fluid regions
+    are constant."""
+    GX, GY, GZ = gdims
+    X, Y, Z = bdims
+    I, J, K = GX // X, GY // Y, GZ // Z
+    dev = "cuda"
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    ph = torch.rand(12, generator=g, device=dev) * (2 * math.pi)
+    xs = torch.arange(GX, device=dev, dtype=torch.float32)
+    ys = torch.arange(GY, device=dev, dtype=torch.float32)
+    # interface height h(x, y): bubbles and spikes at three scales
+    hx = (torch.sin(xs * (2 * math.pi * 3 / GX) + ph[0]) + 0.5 * torch.sin(xs * (2 * math.pi * 11 / GX) + ph[1])
+          + 0.25 * torch.sin(xs * (2 * math.pi * 37 / GX) + ph[2]))
+    hy = (torch.cos(ys * (2 * math.pi * 4 / GY) + ph[3]) + 0.5 * torch.sin(ys * (2 * math.pi * 13 / GY) + ph[4])
+          + 0.25 * torch.cos(ys * (2 * math.pi * 29 / GY) + ph[5]))
+    h = GZ * 0.5 + (GZ / 14.0) * (hx[None, :] + hy[:, None] + 0.6 * torch.sin((xs[None, :] + ys[:, None]) * (2 * math.pi * 7 / GX) + ph[6]))
+    out = torch.empty((I * J * K, Z, Y, X), dtype=torch.uint8, device=dev)
+    thick = GZ / 24.0
+    for b in range(I * J * K):
+        i, j, k = b % I, (b // I) % J, b // (I * J)
+        zz = torch.arange(k * Z, (k + 1) * Z, device=dev, dtype=torch.float32)[:, None, None]
+        hh = h[j * Y:(j + 1) * Y, i * X:(i + 1) * X][None, :, :]
+        d = (zz - hh) / thick
+        if kind == "rm_volume":
+            mix = torch.exp(-d * d)
+            xx = xs[i * X:(i + 1) * X][None, None, :]
+            yy = ys[j * Y:(j + 1) * Y][None, :, None]
+            turb = (torch.sin(xx * 0.37 + zz * 0.21 + ph[7]) * torch.cos(yy * 0.29 - zz * 0.17 + ph[8])
+                    + 0.5 * torch.sin(xx * 0.83 + yy * 0.71 + zz * 0.59 + ph[9]))
+            noise = torch.randint(0, 4, (Z, Y, X), generator=g, device=dev).float()
+            v = 128.0 + 120.0 * torch.tanh(d + 0.8 * mix * turb) + mix * noise
+        else:
+            raise ValueError(kind)
+        out[b] = v.clamp_(0, 255).to(torch.uint8)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bricks", type=int, default=16, help="bricks per GPU")
-    ap.add_argument("--dims", type=int, nargs=3, default=[256, 256, 256])
-    ap.add_argument("--kind", default="rm_like")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--volume", type=int, nargs=3, default=[2048, 2048, 1920], help="global volume per GPU")
+    ap.add_argument("--dims", type=int, nargs=3, default=[256, 256, 128], help="brick dims (main.cpp:78)")
+    ap.add_argument("--bricks", type=int, default=0, help="use only the first N bricks (0 = whole volume)")
+    ap.add_argument("--kind", default="rm_volume")
     ap.add_argument("--tolerance", type=int, default=1)      # main.cpp:254
     ap.add_argument("--max-epochs", type=int, default=2)     # main.cpp:253
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-render", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -74,17 +122,23 @@ def main():
     import __graft_entry__ as g
     g.build()
     import volumerenderer_amd as vr
-    from volumerenderer_amd import _lib
 
-    dims = tuple(args.dims)
-    B = args.bricks
-    V = dims[0] * dims[1] * dims[2]
-    host = make_bricks(args.kind, B, dims, seed=12345 + 1000 * rank)
-    vox = torch.from_numpy(host).cuda().reshape(-1)            # inputs resident in HBM before timing
+    bdims = tuple(args.dims)
+    gdims = tuple(args.volume)
+    V = bdims[0] * bdims[1] * bdims[2]
+    grid = tuple(gdims[a] // bdims[a] for a in range(3))
+    if args.kind in ("rm_volume",):
+        vox4 = make_volume_gpu(torch, gdims, bdims, seed=12345 + 1000 * rank, kind=args.kind)  # rank = timestep
+        if args.bricks:
+            # keep the bricks around the interface first (they are the expensive ones)
+            order = sorted(range(vox4.shape[0]), key=lambda b: abs(b // (grid[0] * grid[1]) - grid[2] // 2))
+            vox4 = vox4[torch.tensor(order[:args.bricks], device="cuda")].contiguous()
+    else:
+        vox4 = torch.from_numpy(make_bricks(args.kind, args.bricks or 16, bdims, seed=12345 + 1000 * rank)).cuda()
+    B = vox4.shape[0]
+    vox = vox4.reshape(-1)                                      # inputs resident in HBM before timing
     out = torch.empty_like(vox)
-    bs = vr.BrickSet(B, dims, args.tolerance, args.max_epochs)
-    L = _lib.lib()
-    stream = torch.cuda.current_stream()
+    bs = vr.BrickSet(B, bdims, args.tolerance, args.max_epochs)
 
     def step():
         bs.build(vox)
@@ -97,12 +151,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    enc_ms = dec_ms = 0.0
     for _ in range(args.steps):
         step()
-        tm = bs.last_timings()                                  # hipEvent timings on the launch stream
-        enc_ms += tm["BUILD"] + tm["COMPRESS"] + tm["PRUNE"] + tm["CONVERT"]
-        dec_ms += tm["DECODE"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -115,41 +165,77 @@ def main():
     total_vox = float(V) * B * world * args.steps
     value = total_vox / dt / 1e6
 
-    # decode kernel roofline: algorithmic bytes = V + ceil(numActiveNodes/4) + (maxTreeDepth+1) per brick
+    # per-kernel timing outside the timed region: hipEvents on the launch stream (vr_brickset_last_timings)
+    enc_ms, dec_ms = [], []
+    for _ in range(3):
+        bs.build(vox)
+        bs.decode(out)
+        tm = bs.last_timings()
+        enc_ms.append(tm["BUILD"] + tm["COMPRESS"] + tm["PRUNE"] + tm["CONVERT"])
+        dec_ms.append(tm["DECODE"])
+        phases = tm
+    # decode kernel roofline: algorithmic bytes = V + ceil(numActiveNodes/4) + (maxTreeDepth+1) per brick (SURVEY 8d)
     alg = 0
     tokens = 0
     for b in range(B):
         inf = bs.info(b)
         alg += V + inf["tree_bytes"] + inf["max_tree_depth"] + 1
         tokens += inf["num_active_nodes"]
-    dec_avg_s = dec_ms / args.steps / 1e3
-    achieved = alg / dec_avg_s / 1e9 if dec_avg_s > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_decode", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    dec_avg_s = sum(dec_ms) / len(dec_ms) / 1e3
+    achieved = alg / dec_avg_s / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_decode_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(dec_avg_s * 1e3, 4)}
 
     res = {"metric": "Mvoxels/s kd-tree compress+decode", "value": round(value, 2), "unit": "Mvoxels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "%d bricks/GPU of %dx%dx%d uint8 (%s), tolerance %d, maxEpochs %d, build+levelCut"
-                      % (B, dims[0], dims[1], dims[2], args.kind, args.tolerance, args.max_epochs),
-                      "tokens_per_voxel": round(tokens / float(V * B), 3)},
-           "encode_ms": round(enc_ms / args.steps, 3), "decode_ms": round(dec_ms / args.steps, 3),
+           "config": {"workload": "%dx%dx%d uint8 volume per GPU as %d bricks of %dx%dx%d (%s), tolerance %d, "
+                      "maxEpochs %d, VolumeKdtree build + levelCut" % (gdims[0], gdims[1], gdims[2], B, bdims[0],
+                                                                         bdims[1], bdims[2], args.kind, args.tolerance,
+                                                                         args.max_epochs),
+                      "tokens_per_voxel": round(tokens / float(V * B), 3),
+                      "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
+           "encode_ms": round(sum(enc_ms) / len(enc_ms), 3), "decode_ms": round(dec_avg_s * 1e3, 3),
+           "phases_ms": {k: round(v, 3) for k, v in phases.items()},
            "roofline": roofline}
+
+    if not args.no_render and not args.bricks and rank == 0:
+        # 1080p ray-cast of the decoded volume (raycaster.frag) on a camera orbit, fps
+        vol = vr.assemble_bricks(out, bdims, np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])]
+                                                        for b in range(B)], np.int64), grid)
+        cam = vr.default_camera()
+        P = vr.default_params(1920, 1080, (256, 256, 128))
+        img = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+        frames = 36
+        for warm in (True, False):
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            for f in range(frames):
+                th = math.radians(f * 10.0)
+                cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
+                cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
+                vr.raycast(vol, gdims, cam, P, img)
+            torch.cuda.synchronize()
+            fps = frames / (time.perf_counter() - r0)
+        res["raycast_1080p_fps"] = round(fps, 1)
+        del vol
 
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as O                         # CPU baseline leg: the oracle as the reference's port
         n_done, t_cpu = 0, 0.0
-        small = host[0]
+        mid = B // 2                                           # bricks around the interface: the representative ones
+        cand = [mid + (q // 2) * (1 if q % 2 == 0 else -1) for q in range(B)]
         while t_cpu < args.cpu_seconds and n_done < B:
+            hb = vox4[cand[n_done] % B].cpu().numpy()
             c0 = time.perf_counter()
-            t = O.OracleTree(host[n_done].copy(), tolerance=args.tolerance, max_epochs=args.max_epochs).build()
+            t = O.OracleTree(hb, tolerance=args.tolerance, max_epochs=args.max_epochs).build()
             t.levelCut()
             t_cpu += time.perf_counter() - c0
             n_done += 1
         res["cpu_baseline"] = {"value": round(n_done * V / t_cpu / 1e6, 3), "unit": "Mvoxels/s", "cores": 1,
-                               "kind": "port", "sample": "%d of the %d bricks, serial build(false)+levelCut, 1 thread"
-                               % (n_done, B)}
+                               "kind": "port", "sample": "%d bricks from the middle of the volume, serial build(false)+"
+                               "levelCut of the CPU oracle, 1 thread, %.1f s" % (n_done, t_cpu)}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
