@@ -112,7 +112,7 @@ static vr_status ensure_encoder_buffers(BrickSet &b)
     b.nErrBlk = ((int64_t)1 << b.D) / 1024 > 0 ? ((int64_t)1 << b.D) / 1024 : 1;
     HIPCHK(hipMalloc(&b.blockErr, B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
     b.estSummStride = ((int64_t)1 << b.D) / 1024 > 0 ? ((int64_t)1 << b.D) / 1024 : 1;
-    HIPCHK(hipMalloc(&b.estSumm, B * (size_t)b.estSummStride * 256));
+    HIPCHK(hipMalloc(&b.estSumm, B * (size_t)b.estSummStride * 128));
     b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256;
     HIPCHK(hipMalloc(&b.blockL1, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));

@@ -199,8 +199,8 @@ __global__ void k_ctrl_init(Ctrl *ctrls)
 //               its exact start state, commits up to the first failure and walks only
 //               that segment node by node.
 #define EST_SEG 1024
-#define EST_CAND 16
-#define EST_ROUNDS 3
+#define EST_CAND 8          // widest candidate window (records hold EST_CAND entries)
+#define EST_ROUNDS 4        // round 0 uses a 4-wide window, later rounds EST_CAND-wide recentred ones
 #define EST_HEAD 4096
 
 struct EstSummary { uint32_t sumS[EST_CAND], sumC[EST_CAND]; int32_t A[EST_CAND], B[EST_CAND]; };
@@ -244,12 +244,12 @@ __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint
     }
 }
 
-// candidate window [base, base+EST_CAND) around the current threshold
-__device__ inline int est_window_base(long long T)
+// candidate window [base, base+nc) around the current threshold
+__device__ inline int est_window_base(long long T, int nc)
 {
-    long long b = T - EST_CAND / 3;
+    long long b = T - (nc <= 4 ? 1 : 2);
     if (b < 0) b = 0;
-    if (b > 256 - EST_CAND) b = 256 - EST_CAND;
+    if (b > 256 - nc) b = 256 - nc;
     return (int)b;
 }
 
@@ -284,14 +284,14 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
             c.estS = S; c.estC = C;
             c.estSeg = EST_HEAD / EST_SEG;
             c.estDone = 0;
-            c.estTbase = est_window_base((long long)(S / (2ull * C + 1ull)));
+            c.estTbase = est_window_base((long long)(S / (2ull * C + 1ull)), 4);
         }
     }
 }
 
 __global__ void __launch_bounds__(256)
-k_est_summ(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb, int64_t leafStride,
-           EstSummary *__restrict__ summ, int64_t summStride)
+k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
+           int64_t leafStride, EstSummary *__restrict__ summ, int64_t summStride)
 {
     const int brick = blockIdx.y, lane = threadIdx.x & 63;
     const Ctrl &c = ctrls[brick];
@@ -314,7 +314,7 @@ k_est_summ(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStr
     const int Tbase = c.estTbase;
     EstSummary *out = summ + (int64_t)brick * summStride + seg;
 #pragma unroll 1
-    for (int ci = 0; ci < EST_CAND; ++ci) {
+    for (int ci = 0; ci < nc; ++ci) {
         const int Th = Tbase + ci;
         int s = 0, cc = 0, a = INT32_MIN, b = INT32_MAX;
 #pragma unroll
@@ -341,7 +341,7 @@ k_est_summ(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStr
 }
 
 __global__ void __launch_bounds__(64)
-k_est_walk(int d, int maxEpochs, int lastRound, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
+k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
            int64_t leafStride, const EstSummary *__restrict__ summ, int64_t summStride)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
@@ -359,11 +359,11 @@ k_est_walk(int d, int maxEpochs, int lastRound, Ctrl *ctrls, const uint8_t *__re
     int fallbacks = 0;
     while (seg < nseg) {
         const long long ci = Tc - Tbase;
-        if (ci < 0 || ci >= EST_CAND) {      // threshold left the candidate window
+        if (ci < 0 || ci >= nc) {            // threshold left the candidate window
             if (!lastRound) {                // next round: new summaries around the new threshold
                 if (lane == 0) {
                     c.estS = S; c.estC = C; c.estSeg = (int)seg;
-                    c.estTbase = est_window_base(Tc);
+                    c.estTbase = est_window_base(Tc, ncNext);
                     c.estFallbacks += fallbacks;
                 }
                 return;
@@ -1136,10 +1136,11 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
         if (n > EST_HEAD) {
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
             for (int r = 0; r < EST_ROUNDS; ++r) {
-                hipLaunchKernelGGL(k_est_summ, dim3(cdiv(nseg, 4), B), dim3(256), 0, st, d, s.ctrl, s.temp,
+                const int nc = r == 0 ? 4 : EST_CAND;
+                hipLaunchKernelGGL(k_est_summ, dim3(cdiv(nseg, 4), B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
                                    bs->heapStride, rb, bs->leafStride, (EstSummary *)bs->estSumm, bs->estSummStride);
-                hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, r == EST_ROUNDS - 1 ? 1 : 0,
-                                   s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
+                hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, EST_CAND,
+                                   r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
                                    (const EstSummary *)bs->estSumm, bs->estSummStride);
             }
         }
