@@ -706,6 +706,80 @@ k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRan
     }
 }
 
+// Leaf prune + the 12 levels above it in one block (the level-synchronous kernels above
+// stay for small bricks and for the levels nearer the root): 16 leaves per thread as
+// 16-byte loads, pruned flags carried upwards in LDS, each level's codes read-modified-
+// written in place.  Equal to the serial recursion (R.cpp:596-629) because a node only
+// depends on its two children.
+__global__ void __launch_bounds__(256)
+k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
+          uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride)
+{
+    __shared__ uint8_t fl[2][2048];
+    const int brick = blockIdx.y, t = threadIdx.x;
+    Ctrl &c = ctrls[brick];
+    const uint32_t base = blockIdx.x << 12;
+    uint8_t *Cb = codes + (int64_t)brick * heapStride;
+    uint8_t *CR = codesRange ? codesRange + (int64_t)brick * heapStride : nullptr;
+    const int64_t li = ((int64_t)1 << D) + base + t * 16;
+    uint4 cv = *(const uint4 *)(Cb + li);
+    const uint4 tv = *(const uint4 *)(temp + (int64_t)brick * heapStride + li);
+    const uint4 rv = *(const uint4 *)(rb.b[c.par] + (int64_t)brick * leafStride + base + t * 16);
+    uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    int maxErr = 0;
+    uint32_t pr = 0;            // pruned flags of my 16 leaves
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int sh = (k & 3) * 8;
+        const int code = (cw[k >> 2] >> sh) & 255, tt = (tw[k >> 2] >> sh) & 255, rec = (rw[k >> 2] >> sh) & 255;
+        const int err = rec > tt ? rec - tt : tt - rec;
+        maxErr = err > maxErr ? err : maxErr;
+        if (code == 0 && err < tol) {       // R.cpp:618-626
+            cw[k >> 2] |= 3u << sh;
+            pr |= 1u << k;
+        } else if (code == 3) pr |= 1u << k;
+    }
+    *(uint4 *)(Cb + li) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    if (CR) {
+        uint4 q = *(const uint4 *)(CR + li);
+        uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if ((pr >> k) & 1u) qw[k >> 2] |= 3u << ((k & 3) * 8);   // M.cpp:864-865
+        *(uint4 *)(CR + li) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(maxErr, o); maxErr = u > maxErr ? u : maxErr; }
+    if ((t & 63) == 0 && maxErr > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, maxErr);
+    // level D-1: 8 nodes per thread, children flags in registers
+    {
+        const int64_t ni = ((int64_t)1 << (D - 1)) + (base >> 1) + t * 8;
+        unsigned long long v = *(const unsigned long long *)(Cb + ni), vr = CR ? *(const unsigned long long *)(CR + ni) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool both = ((pr >> (2 * k)) & 3u) == 3u;
+            const int code = (int)((v >> (8 * k)) & 255ull);
+            const bool p = both && code == 0;
+            if (p) { v |= 3ull << (8 * k); vr |= 3ull << (8 * k); }
+            fl[1][t * 8 + k] = (uint8_t)((p || code == 3) ? 1 : 0);
+        }
+        *(unsigned long long *)(Cb + ni) = v;
+        if (CR) *(unsigned long long *)(CR + ni) = vr;
+    }
+    __syncthreads();
+    for (int l = 2; l <= 12; ++l) {
+        const int m = 4096 >> l, src = (l - 1) & 1, dst = l & 1;
+        const int64_t lvl = ((int64_t)1 << (D - l)) + (base >> l);
+        for (int i = t; i < m; i += 256) {
+            const bool both = fl[src][2 * i] && fl[src][2 * i + 1];
+            const int code = Cb[lvl + i];
+            const bool p = both && code == 0;
+            if (p) { Cb[lvl + i] = 3; if (CR) CR[lvl + i] = 3; }
+            fl[dst][i] = (uint8_t)((p || code == 3) ? 1 : 0);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- convert ----
 // Tokens owned by leaf rank r, in stream order: the live internal nodes whose first
 // leaf is r (depth ascending), then the leaf token and its grown chain (R.cpp:655-704).
@@ -1232,10 +1306,17 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // ---- PRUNE
     ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
-    hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
-                       bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
-                       bs->leafStride);
-    for (int d = D - 1; d >= 0; --d)
+    int pruneFrom = D - 1;
+    if (D >= 12) {
+        hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
+                           bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
+                           bs->leafStride);
+        pruneFrom = D - 13;
+    } else
+        hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
+                           bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
+                           bs->leafStride);
+    for (int d = pruneFrom; d >= 0; --d)
         hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.codes,
                            mr ? bs->rng.codes : nullptr, bs->heapStride);
     hipLaunchKernelGGL(k_fix_chain_distances, dim3(B), dim3(64), 0, st, D, bs->maxDepth, bs->mid.ctrl,
