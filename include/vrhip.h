@@ -185,6 +185,15 @@ vr_status vr_raycast(const uint8_t *volume_dev, const int64_t dims[3], const vr_
  * (c1 + t1*c2, t1*t2); and the final colour transfer of raycaster.frag:82-85. */
 vr_status vr_composite_over(float *front_dev, const float *back_dev, int64_t num_pixels, void *stream);
 vr_status vr_composite_finish(const float *partial_dev, float *rgba_dev, int64_t num_pixels, void *stream);
+/* Direct-send sort-last compositing of one image tile: partials_dev holds num_slabs partial images
+ * of this tile back to back (num_pixels*4 floats each, slab s = the s-th slab along `axis` of the
+ * volume).  Every pixel combines them front to back in ITS view order (ascending slab index where
+ * the pixel's ray direction along `axis` is >= 0, descending otherwise -- "over" is associative but
+ * not commutative) and applies the colour transfer.  first_pixel = row-major index of the tile's
+ * first pixel in the width*height frame described by params. */
+vr_status vr_composite_slabs(const float *partials_dev, int32_t num_slabs, int64_t num_pixels, int64_t first_pixel,
+                             int32_t axis, const vr_camera *cam, const vr_render_params *params, float *rgba_dev,
+                             void *stream);
 
 /* ---- instrumentation (the reference's DebugTimer phases, R.cpp:47-113) ----------
  * Milliseconds of the last build / decode measured with hipEvents on the call's stream:

@@ -96,6 +96,7 @@ def lib():
         L.vro_render.restype = C.c_int
         L.vro_composite_over.argtypes = [p, p, i64]
         L.vro_composite_finish.argtypes = [p, p, i64]
+        L.vro_composite_slabs.argtypes = [p, C.c_int, i64, i64, C.c_int, C.POINTER(Camera), C.c_int, C.c_int, p]
     _lib = L
     return L
 
@@ -306,4 +307,13 @@ def composite_finish(partial):
     p_ = np.ascontiguousarray(partial, np.float32)
     out = np.empty_like(p_)
     lib().vro_composite_finish(p_.ctypes.data, out.ctypes.data, p_.size // 4)
+    return out
+
+
+def composite_slabs(partials, first_pixel, axis, cam, width, height):
+    """partials: float32 [num_slabs][npix][4]; returns [npix][4] (reference of vr_composite_slabs)."""
+    a = np.ascontiguousarray(partials, np.float32)
+    out = np.empty(a.shape[1:], np.float32)
+    lib().vro_composite_slabs(a.ctypes.data, a.shape[0], a.shape[1], int(first_pixel), int(axis), C.byref(cam),
+                              int(width), int(height), out.ctypes.data)
     return out

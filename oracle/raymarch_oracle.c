@@ -220,3 +220,31 @@ void vro_composite_finish(const float *partial, float *rgba, int64_t npix)
         } else { rgba[4 * i] = rgba[4 * i + 1] = rgba[4 * i + 2] = rgba[4 * i + 3] = 1.0f; }
     }
 }
+
+/* per-pixel view-ordered composite of num_slabs partial tiles (test reference of vr_composite_slabs) */
+void vro_composite_slabs(const float *partials, int num_slabs, int64_t npix, int64_t first, int axis,
+                         const vro_camera *cam, int W, int H, float *rgba)
+{
+    float f[3] = { cam->front[0], cam->front[1], cam->front[2] }, s[3], u[3];
+    norm3(f);
+    cross3(f, cam->up, s);
+    norm3(s);
+    cross3(s, f, u);
+    const float rad = cam->fov_deg * 0.01745329251994329576923690768489f;
+    const float tanY = tanf(0.5f * rad), tanX = tanY * (float)W / (float)H;
+    for (int64_t i = 0; i < npix; ++i) {
+        int64_t gp = first + i;
+        int px = (int)(gp % W), py = (int)(gp / W);
+        float nx = 2.0f * ((float)px + 0.5f) / (float)W - 1.0f, ny = 1.0f - 2.0f * ((float)py + 0.5f) / (float)H;
+        float d = f[axis] + nx * tanX * s[axis] + ny * tanY * u[axis];
+        float c = 0.0f, tau = 1.0f, cov = 0.0f;
+        for (int k = 0; k < num_slabs; ++k) {
+            int sidx = d >= 0.0f ? k : num_slabs - 1 - k;
+            const float *p = partials + 4 * ((int64_t)sidx * npix + i);
+            c = c + tau * p[0]; tau = tau * p[1]; cov = fmaxf(cov, p[2]);
+        }
+        float *o = rgba + 4 * i;
+        if (cov > 0.0f) { o[0] = 1.0f - c; o[1] = 1.0f - c; o[2] = 1.0f; o[3] = 1.0f - tau; }
+        else { o[0] = o[1] = o[2] = o[3] = 1.0f; }
+    }
+}

@@ -72,6 +72,7 @@ SIGNATURES = {
     "vr_raycast": (_I32, [_P, C.POINTER(_I64), C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
     "vr_composite_over": (_I32, [_P, _P, _I64, _P]),
     "vr_composite_finish": (_I32, [_P, _P, _I64, _P]),
+    "vr_composite_slabs": (_I32, [_P, _I32, _I64, _I64, _I32, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
     "vr_brickset_last_timings": (_I32, [_P, C.POINTER(C.c_float)]),
 }
 

@@ -15,6 +15,7 @@ namespace vr {
 int raycast_launch(const uint8_t *, const int64_t dims[3], const vr_camera *, const vr_render_params *, float *, hipStream_t);
 int composite_over_launch(float *, const float *, int64_t, hipStream_t);
 int composite_finish_launch(const float *, float *, int64_t, hipStream_t);
+int composite_slabs_launch(const float *, int, int64_t, int64_t, int, const vr_camera *, const vr_render_params *, float *, hipStream_t);
 int assemble_launch(bool, const uint8_t *, uint8_t *, int, const int64_t bd[3], const int64_t *, const int64_t grid[3], hipStream_t);
 int measure_error_launch(const uint8_t *, const uint8_t *, int64_t, int *, unsigned long long *, hipStream_t);
 int query_error_launch(const uint8_t *, const uint8_t *, int64_t, uint8_t *, hipStream_t);
@@ -513,6 +514,17 @@ vr_status vr_composite_finish(const float *partial, float *rgba, int64_t n, void
     if (!partial || !rgba || n <= 0) return VR_ERR_INVALID;
     if (!device_ok()) return VR_ERR_NO_DEVICE;
     return composite_finish_launch(partial, rgba, n, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+vr_status vr_composite_slabs(const float *partials, int32_t num_slabs, int64_t num_pixels, int64_t first_pixel, int32_t axis,
+                             const vr_camera *cam, const vr_render_params *P, float *rgba, void *stream)
+{
+    if (!partials || !cam || !P || !rgba || num_slabs <= 0 || num_pixels <= 0 || first_pixel < 0 || axis < 0 || axis > 2)
+        return VR_ERR_INVALID;
+    if (P->width <= 0 || P->height <= 0 || first_pixel + num_pixels > (int64_t)P->width * P->height) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    return composite_slabs_launch(partials, num_slabs, num_pixels, first_pixel, axis, cam, P, rgba, (hipStream_t)stream) == 0
+               ? VR_OK : VR_ERR_NO_DEVICE;
 }
 
 vr_status vr_brickset_last_timings(vr_brickset *h, float ms[5])

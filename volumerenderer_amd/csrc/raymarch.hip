@@ -192,6 +192,42 @@ __global__ void k_composite_finish(const float4 *partial, float4 *rgba, int64_t 
     rgba[i] = o;
 }
 
+static void cross3(const float *a, const float *b, float *o);
+static void hnorm3(float *v);
+
+struct SlabArgs {
+    const float4 *partials;
+    int num_slabs;
+    int64_t npix, first;
+    int axis, W, H;
+    float f[3], s[3], u[3], tanX, tanY;
+    float4 *out;
+};
+
+__global__ void __launch_bounds__(256)
+k_composite_slabs(SlabArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.npix) return;
+    const int64_t gp = a.first + i;
+    const int px = (int)(gp % a.W), py = (int)(gp / a.W);
+    const float nx = 2.0f * ((float)px + 0.5f) / (float)a.W - 1.0f;
+    const float ny = 1.0f - 2.0f * ((float)py + 0.5f) / (float)a.H;
+    const float d = a.f[a.axis] + nx * a.tanX * a.s[a.axis] + ny * a.tanY * a.u[a.axis];
+    float c = 0.0f, tau = 1.0f, cov = 0.0f;
+    for (int k = 0; k < a.num_slabs; ++k) {
+        const int sidx = d >= 0.0f ? k : a.num_slabs - 1 - k;
+        const float4 p = a.partials[(int64_t)sidx * a.npix + i];
+        c = c + tau * p.x;          // (c1 + t1*c2, t1*t2)
+        tau = tau * p.y;
+        cov = fmaxf(cov, p.z);
+    }
+    float4 o;
+    if (cov > 0.0f) { o.x = 1.0f - c; o.y = 1.0f - c; o.z = 1.0f; o.w = 1.0f - tau; }   // raycaster.frag:82-85
+    else { o.x = o.y = o.z = o.w = 1.0f; }
+    a.out[i] = o;
+}
+
 // Brick <-> global volume placement (VolumeReader.h:172-211), 16-byte rows segments.
 template <bool TO_VOLUME>
 __global__ void __launch_bounds__(256)
@@ -271,6 +307,25 @@ int raycast_launch(const uint8_t *vol, const int64_t dims[3], const vr_camera *c
     dim3 grid((P->width + 7) / 8, (P->height + 7) / 8);
     hipLaunchKernelGGL(k_raycast, grid, dim3(64), 0, st, a);
     return launch_status("raymarch");
+}
+
+int composite_slabs_launch(const float *partials, int nslabs, int64_t npix, int64_t first, int axis, const vr_camera *cam,
+                           const vr_render_params *P, float *rgba, hipStream_t st)
+{
+    SlabArgs a;
+    a.partials = (const float4 *)partials; a.num_slabs = nslabs; a.npix = npix; a.first = first;
+    a.axis = axis; a.W = P->width; a.H = P->height;
+    for (int k = 0; k < 3; ++k) a.f[k] = cam->front[k];
+    hnorm3(a.f);
+    cross3(a.f, cam->up, a.s);
+    hnorm3(a.s);
+    cross3(a.s, a.f, a.u);
+    const float rad = cam->fov_deg * 0.01745329251994329576923690768489f;
+    a.tanY = tanf(0.5f * rad);
+    a.tanX = a.tanY * (float)P->width / (float)P->height;
+    a.out = (float4 *)rgba;
+    hipLaunchKernelGGL(k_composite_slabs, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, a);
+    return launch_status("composite_slabs");
 }
 
 int composite_over_launch(float *front, const float *back, int64_t n, hipStream_t st)
