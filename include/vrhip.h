@@ -80,6 +80,14 @@ vr_status vr_set_device(int32_t device);
 const char *vr_status_string(vr_status s);
 const char *vr_version(void);
 
+/* ---- device buffers for host code that does not include HIP headers ----------------
+ * (the reference's host code hands over std::vector<byte>; the facade in include/vrhip/
+ * stages it through these).  Copies synchronise `stream` before returning. */
+vr_status vr_malloc(void **dev, int64_t bytes);
+vr_status vr_free(void *dev);
+vr_status vr_upload(void *dst_dev, const void *src_host, int64_t bytes, void *stream);
+vr_status vr_download(void *dst_host, const void *src_dev, int64_t bytes, void *stream);
+
 /* ---- brickset life cycle ------------------------------------------------------
  * VolumeKdtree(std::vector<byte>&, x, y, z) + setErrorTolerance + setMaxEpochs
  * (VolumeKdtree_recover.h:103-112, R.cpp:9-15).  dims must be powers of two

@@ -50,6 +50,10 @@ SIGNATURES = {
     "vr_set_device": (_I32, [_I32]),
     "vr_status_string": (C.c_char_p, [_I32]),
     "vr_version": (C.c_char_p, []),
+    "vr_malloc": (_I32, [C.POINTER(_P), _I64]),
+    "vr_free": (_I32, [_P]),
+    "vr_upload": (_I32, [_P, _P, _I64, _P]),
+    "vr_download": (_I32, [_P, _P, _I64, _P]),
     "vr_brickset_create": (_I32, [C.POINTER(_P), _I32, C.POINTER(_I64), _I32, _I32, _I32]),
     "vr_brickset_destroy": (_I32, [_P]),
     "vr_brickset_set_error_tolerance": (_I32, [_P, _I32]),

@@ -69,6 +69,35 @@ const char *vr_status_string(vr_status s)
 
 const char *vr_version(void) { return "vrhip 0.1 (gfx950)"; }
 
+vr_status vr_malloc(void **dev, int64_t bytes)
+{
+    if (!dev || bytes <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    HIPCHK(hipMalloc(dev, (size_t)bytes));
+    return VR_OK;
+}
+vr_status vr_free(void *dev)
+{
+    if (dev) hipFree(dev);
+    return VR_OK;
+}
+vr_status vr_upload(void *dst, const void *src, int64_t bytes, void *stream)
+{
+    if (!dst || !src || bytes <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VR_OK;
+}
+vr_status vr_download(void *dst, const void *src, int64_t bytes, void *stream)
+{
+    if (!dst || !src || bytes <= 0) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VR_OK;
+}
+
 static void free_stream2(Stream2 &s)
 {
     hipFree(s.temp); hipFree(s.codes);
