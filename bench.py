@@ -62,9 +62,7 @@ def make_volume_gpu(torch, gdims, bdims, seed, kind="rm_volume"):
     X, Y, Z = bdims
     I, J, K = GX // X, GY // Y, GZ // Z
     dev = "cuda"
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    ph = torch.rand(12, generator=g, device=dev) * (2 * math.pi)
+    ph = [float(v) for v in np.random.default_rng(seed).random(12) * (2 * math.pi)]   # host RNG: phases only
     xs = torch.arange(GX, device=dev, dtype=torch.float32)
     ys = torch.arange(GY, device=dev, dtype=torch.float32)
     # interface height h(x, y): bubbles and spikes at three scales
@@ -73,25 +71,36 @@ def make_volume_gpu(torch, gdims, bdims, seed, kind="rm_volume"):
     hy = (torch.cos(ys * (2 * math.pi * 4 / GY) + ph[3]) + 0.5 * torch.sin(ys * (2 * math.pi * 13 / GY) + ph[4])
           + 0.25 * torch.cos(ys * (2 * math.pi * 29 / GY) + ph[5]))
     h = GZ * 0.5 + (GZ / 14.0) * (hx[None, :] + hy[:, None] + 0.6 * torch.sin((xs[None, :] + ys[:, None]) * (2 * math.pi * 7 / GX) + ph[6]))
-    out = torch.empty((I * J * K, Z, Y, X), dtype=torch.uint8, device=dev)
     thick = GZ / 24.0
-    for b in range(I * J * K):
-        i, j, k = b % I, (b // I) % J, b // (I * J)
-        zz = torch.arange(k * Z, (k + 1) * Z, device=dev, dtype=torch.float32)[:, None, None]
-        hh = h[j * Y:(j + 1) * Y, i * X:(i + 1) * X][None, :, :]
-        d = (zz - hh) / thick
-        if kind == "rm_volume":
-            mix = torch.exp(-d * d)
-            xx = xs[i * X:(i + 1) * X][None, None, :]
-            yy = ys[j * Y:(j + 1) * Y][None, :, None]
-            turb = (torch.sin(xx * 0.37 + zz * 0.21 + ph[7]) * torch.cos(yy * 0.29 - zz * 0.17 + ph[8])
-                    + 0.5 * torch.sin(xx * 0.83 + yy * 0.71 + zz * 0.59 + ph[9]))
-            noise = torch.randint(0, 4, (Z, Y, X), generator=g, device=dev).float()
-            v = 128.0 + 120.0 * torch.tanh(d + 0.8 * mix * turb) + mix * noise
-        else:
+    vol = torch.empty((GZ, GY, GX), dtype=torch.uint8, device=dev)
+    xi = torch.arange(GX, device=dev, dtype=torch.int64)[None, None, :]
+    yi = torch.arange(GY, device=dev, dtype=torch.int64)[None, :, None]
+    xx, yy = xs[None, None, :], ys[None, :, None]
+    CH = 32                                   # z-chunk: few, large kernels (a counter-collecting
+    for z0 in range(0, GZ, CH):               # profiler dies on tens of thousands of tiny dispatches)
+        z1 = min(GZ, z0 + CH)
+        zz = torch.arange(z0, z1, device=dev, dtype=torch.float32)[:, None, None]
+        d = (zz - h[None, :, :]) / thick
+        if kind != "rm_volume":
             raise ValueError(kind)
-        out[b] = v.clamp_(0, 255).to(torch.uint8)
-    return out
+        mix = torch.exp(-d * d)
+        turb = (torch.sin(xx * 0.37 + zz * 0.21 + ph[7]) * torch.cos(yy * 0.29 - zz * 0.17 + ph[8])
+                + 0.5 * torch.sin(xx * 0.83 + yy * 0.71 + zz * 0.59 + ph[9]))
+        # 2-bit noise from an integer hash of the global voxel coordinate (no device RNG: reproducible
+        # on every device)
+        zi = torch.arange(z0, z1, device=dev, dtype=torch.int64)[:, None, None]
+        hsh = (xi * 73856093) ^ (yi * 19349663) ^ (zi * 83492791) ^ (seed * 2654435761)
+        hsh = (hsh ^ (hsh >> 13)) * 1274126177
+        noise = ((hsh >> 16) & 3).float()
+        v = 128.0 + 120.0 * torch.tanh(d + 0.8 * mix * turb) + mix * noise
+        vol[z0:z1] = v.clamp_(0, 255).to(torch.uint8)
+        del d, mix, turb, hsh, noise, v
+    # global volume -> contiguous bricks (inverse of VolumeReader::LoadBricksToTexture placement)
+    import volumerenderer_amd as vr
+    ijk = np.array([[b % I, (b // I) % J, b // (I * J)] for b in range(I * J * K)], np.int64)
+    out = vr.disassemble_bricks(vol.reshape(-1), bdims, ijk, (I, J, K))
+    del vol
+    return out.reshape(I * J * K, Z, Y, X)
 
 
 def main():
@@ -110,6 +119,8 @@ def main():
     ap.add_argument("--no-render", action="store_true")
     args = ap.parse_args()
 
+    import __graft_entry__ as g
+    g.build()                      # before anything touches the GPU (a rebuild execs hipcc)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -119,8 +130,6 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    import __graft_entry__ as g
-    g.build()
     import volumerenderer_amd as vr
 
     bdims = tuple(args.dims)
@@ -183,8 +192,19 @@ def main():
         tokens += inf["num_active_nodes"]
     dec_avg_s = sum(dec_ms) / len(dec_ms) / 1e3
     achieved = alg / dec_avg_s / 1e9
+    # HBM traffic of the decode launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+    # --pmc WRITE_SIZE runs of this same command, profiles/): only quoted when the workload is the profiled one
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        if args.kind == "rm_volume" and not args.bricks and gdims == (2048, 2048, 1920) and bdims == (256, 256, 128) \
+                and args.tolerance == 1 and args.max_epochs == 2:
+            traffic = pm["decode_traffic_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "k_decode_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_hbm_traffic.json (bytes per launch)" if traffic else None,
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(dec_avg_s * 1e3, 4)}
 
     res = {"metric": "Mvoxels/s kd-tree compress+decode", "value": round(value, 2), "unit": "Mvoxels/s",

@@ -15,13 +15,23 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 _lib = None
 
 
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for s in ("kdtree_oracle.c", "raymarch_oracle.c", "Makefile"):
+        h.update(open(os.path.join(_HERE, s), "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    """Compile liboracle.so with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH) or any(
-        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH)
-        for s in ("kdtree_oracle.c", "raymarch_oracle.c", "Makefile")
-    ):
+    """Compile liboracle.so with gcc (oracle/Makefile).  Staleness is a content hash (mtimes do
+    not survive the copy to a GPU box)."""
+    stamp = _LIB_PATH + ".srchash"
+    fresh = os.path.exists(_LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == _source_hash()
+    if force or not fresh:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(_source_hash())
     return _LIB_PATH
 
 

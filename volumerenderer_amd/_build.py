@@ -13,11 +13,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+STAMP = LIB + ".srchash"
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    # content hash, not mtimes: the snapshot shipped to a GPU box does not keep mtimes, and a
+    # needless rebuild there would exec hipcc from a process that may already hold the GPU
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return open(STAMP).read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
@@ -28,6 +40,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash())
     return LIB
 
 
