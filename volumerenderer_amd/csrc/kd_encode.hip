@@ -313,6 +313,13 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     }
     const int Tbase = c.estTbase;
     EstSummary *out = summ + (int64_t)brick * summStride + seg;
+    uint32_t anyPd = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) anyPd |= (uint32_t)pd[k];
+    if (__ballot(anyPd != 0) == 0ull) {      // parents reproduce the truths exactly (constant regions): nothing counts
+        if (lane < nc) { out->sumS[lane] = 0; out->sumC[lane] = 0; out->A[lane] = 0; out->B[lane] = 0; }
+        return;
+    }
 #pragma unroll 1
     for (int ci = 0; ci < nc; ++ci) {
         const int Th = Tbase + ci;
@@ -864,6 +871,7 @@ struct EmitArgs {
     int D, maxDepth, tol, Ds, K;
     uint32_t *blockTot, *blockOff;
     unsigned long long *blockL1;   // per-block sum |recon - temp| after growth (reduced by k_emit_stats)
+    uint8_t *blockAlive;           // k_block_alive
     int64_t nEmitBlk;
     uint8_t *tree, *treeR;
     int64_t treeCap;
@@ -1065,19 +1073,21 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
     Quad Q;
     Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0; Q.maxErr = 0; Q.l1 = 0;
     const int jmin = r0 ? D - (__ffs((int)r0) - 1) : 0;          // <= D-2
-    bool alive = true;
-    if (jmin > 0) alive = Cb[((int64_t)1 << (jmin - 1)) + (r0 >> (D - jmin + 1))] != 3;
-    for (int j = jmin; alive && j <= D - 2; ++j) {                 // spine down to the quad's depth-(D-2) node
-        if (j == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
-        const int code = Cb[((int64_t)1 << j) + (r0 >> (D - j))];
-        str_put(Q.s, (uint32_t)code, 1);
-        if (code == 3) alive = false;
-    }
-    if (!alive) return Q;
+    // every load is issued before any is looked at: one memory latency instead of a dependent chain
+    const int parentCode = jmin > 0 ? Cb[((int64_t)1 << (jmin - 1)) + (r0 >> (D - jmin + 1))] : 0;
+    const int quadCode = Cb[((int64_t)1 << (D - 2)) + (r0 >> 2)];
     const uint32_t pair = *(const uint16_t *)(Cb + ((int64_t)1 << (D - 1)) + (r0 >> 1));
     const uint32_t cl = *(const uint32_t *)(Cb + ((int64_t)1 << D) + r0);
     const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
     const uint32_t rl = *(const uint32_t *)(Rl + r0);
+    bool alive = parentCode != 3;
+    for (int j = jmin; alive && j <= D - 2; ++j) {                 // spine down to the quad's depth-(D-2) node
+        if (j == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
+        const int code = j == D - 2 ? quadCode : Cb[((int64_t)1 << j) + (r0 >> (D - j))];
+        str_put(Q.s, (uint32_t)code, 1);
+        if (code == 3) alive = false;
+    }
+    if (!alive) return Q;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int pc = (pair >> (8 * h)) & 255;
@@ -1098,7 +1108,9 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
                     const int err = rec > t ? rec - t : t - rec;
                     if (err > tol) {
                         ++depth;
-                        const Enc en = encode_node(t, rec, dmap[depth]);
+                        // distanceMap[D+1..D+7] is 64,32,..,1 by construction (R.cpp:23,94-97): no memory load
+                        // inside this dependent loop
+                        const Enc en = encode_node(t, rec, 64 >> (depth - D - 1));
                         rec = en.recon;
                         bits |= (uint32_t)en.code << (2 * nt);
                         ++nt;
@@ -1114,6 +1126,29 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
     return Q;
 }
 
+// One flag per 1024-rank emit block: does its depth-(D-10) subtree emit anything at all?
+// No iff a proper ancestor of that subtree's root was pruned and this block does not hold
+// that ancestor's first leaf (the pruned ancestor's own token belongs to the block that does).
+// Lets k_emit4 skip the constant regions of a volume without touching their leaf arrays.
+__global__ void __launch_bounds__(256)
+k_block_alive(EmitArgs a, int64_t nblk)
+{
+    const int brick = blockIdx.y;
+    const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nblk) return;
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const int dl = a.D - 10;
+    bool alive = true;
+    for (int j = 0; j < dl; ++j) {
+        if (Cb[((int64_t)1 << j) + (blk >> (dl - j))] == 3) {
+            // first pruned node on the path: it is emitted itself, by the block holding ITS first leaf
+            alive = ((blk >> (dl - j)) << (dl - j)) == blk;
+            break;
+        }
+    }
+    a.blockAlive[(int64_t)brick * a.nEmitBlk + blk] = alive ? 1 : 0;
+}
+
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_emit4(EmitArgs a)
@@ -1127,6 +1162,18 @@ k_emit4(EmitArgs a)
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
     const uint32_t r0 = blockIdx.x * EMIT4_RANKS + threadIdx.x * 4;
+    if (!a.blockAlive[(int64_t)brick * a.nEmitBlk + blockIdx.x]) {          // wave-uniform: nothing to emit here
+        if (!WRITE) { if (threadIdx.x == 0) a.blockTot[(int64_t)brick * a.nEmitBlk + blockIdx.x] = 0; return; }
+        if (threadIdx.x == 0) a.blockL1[(int64_t)brick * a.nEmitBlk + blockIdx.x] = 0;
+        if ((r0 & ((1u << a.K) - 1u)) == 0) {     // index entries of a dead region: value of the pruned ancestor
+            const uint32_t sidx = r0 >> a.K;
+            int val = c.distanceMap[0];
+            for (int j = 1; j <= a.Ds; ++j) val = apply_code(val, Cb[((int64_t)1 << j) + (sidx >> (a.Ds - j))], c.distanceMap[j]);
+            a.idxOff[(int64_t)brick * a.nIdx + sidx] = VR_IDX_DEAD;
+            a.idxVal[(int64_t)brick * a.nIdx + sidx] = (uint8_t)val;
+        }
+        return;
+    }
     if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
     const Quad Q = quad_tokens(Cb, Tb, Rl, a.D, a.maxDepth, a.tol, c.distanceMap, a.Ds, r0);
     uint32_t tot;
@@ -1332,11 +1379,15 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
     a.blockL1 = bs->blockL1;
+    a.blockAlive = bs->blockAlive;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
     const bool quad = !mr && D >= 12 && bs->K >= 2;
     const int64_t nblk = cdiv((int64_t)1 << D, quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK);
-    if (quad) hipLaunchKernelGGL(k_emit4<false>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    if (quad) {
+        hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
+        hipLaunchKernelGGL(k_emit4<false>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    }
     else hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
