@@ -33,7 +33,8 @@ struct BrickSet {
     void *estSumm = nullptr;     // B * estSummStride EstSummary records (estimator, kd_encode.hip)
     int64_t estSummStride = 0;
     unsigned long long *blockL1 = nullptr; // B * nEmitBlk
-    uint8_t *blockAlive = nullptr;          // B * nEmitBlk
+    uint8_t *blockAlive = nullptr, *blockVal = nullptr;   // B * nEmitBlk
+    unsigned long long *blockSpine = nullptr; // B * nEmitBlk
     uint32_t *blockTot = nullptr, *blockOff = nullptr; // B * nEmitBlk
     int64_t nEmitBlk = 0;
     uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)

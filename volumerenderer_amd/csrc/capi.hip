@@ -146,6 +146,8 @@ static vr_status ensure_encoder_buffers(BrickSet &b)
     b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256;
     HIPCHK(hipMalloc(&b.blockL1, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&b.blockAlive, B * (size_t)b.nEmitBlk));
+    HIPCHK(hipMalloc(&b.blockVal, B * (size_t)b.nEmitBlk));
+    HIPCHK(hipMalloc(&b.blockSpine, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     return VR_OK;
@@ -158,7 +160,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_stream2(b.mid);
     free_stream2(b.rng);
     for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
-    hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive);
+    hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine);
     hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.lut);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;

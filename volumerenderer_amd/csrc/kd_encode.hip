@@ -723,11 +723,18 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
           uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride)
 {
     __shared__ uint8_t fl[2][2048];
+    __shared__ uint8_t lv[2048], lvOld[2048];     // codes of the block's nodes at depths D-12 .. D-2, heap order
     const int brick = blockIdx.y, t = threadIdx.x;
     Ctrl &c = ctrls[brick];
     const uint32_t base = blockIdx.x << 12;
     uint8_t *Cb = codes + (int64_t)brick * heapStride;
     uint8_t *CR = codesRange ? codesRange + (int64_t)brick * heapStride : nullptr;
+    for (int h = 1 + t; h < 2048; h += 256) {
+        const int lq = 31 - __clz(h);
+        const uint8_t cv0 = Cb[((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq))];
+        lv[h] = cv0;
+        lvOld[h] = cv0;
+    }
     const int64_t li = ((int64_t)1 << D) + base + t * 16;
     uint4 cv = *(const uint4 *)(Cb + li);
     const uint4 tv = *(const uint4 *)(temp + (int64_t)brick * heapStride + li);
@@ -773,17 +780,25 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         if (CR) *(unsigned long long *)(CR + ni) = vr;
     }
     __syncthreads();
+    // levels D-2 .. D-12 of this block (2047 codes) were fetched into LDS up front (one memory
+    // round trip instead of eleven dependent ones); prune them there and write them back once
     for (int l = 2; l <= 12; ++l) {
         const int m = 4096 >> l, src = (l - 1) & 1, dst = l & 1;
-        const int64_t lvl = ((int64_t)1 << (D - l)) + (base >> l);
+        const int hb = 1 << (12 - l);               // heap base of this level inside the block
         for (int i = t; i < m; i += 256) {
             const bool both = fl[src][2 * i] && fl[src][2 * i + 1];
-            const int code = Cb[lvl + i];
+            const int code = lv[hb + i];
             const bool p = both && code == 0;
-            if (p) { Cb[lvl + i] = 3; if (CR) CR[lvl + i] = 3; }
+            if (p) lv[hb + i] = 3;
             fl[dst][i] = (uint8_t)((p || code == 3) ? 1 : 0);
         }
         __syncthreads();
+    }
+    for (int h = 1 + t; h < 2048; h += 256) {
+        const int lq = 31 - __clz(h);               // depth below the block root
+        const int64_t gi = ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq));
+        const uint8_t nv = lv[h];
+        if (nv != lvOld[h]) { Cb[gi] = nv; if (CR) CR[gi] = 3; }
     }
 }
 
@@ -871,7 +886,8 @@ struct EmitArgs {
     int D, maxDepth, tol, Ds, K;
     uint32_t *blockTot, *blockOff;
     unsigned long long *blockL1;   // per-block sum |recon - temp| after growth (reduced by k_emit_stats)
-    uint8_t *blockAlive;           // k_block_alive
+    uint8_t *blockAlive, *blockVal; // k_block_alive: flags, scalar above the block
+    unsigned long long *blockSpine; // k_block_alive: tokens above depth D-10 owned by the block's first rank
     int64_t nEmitBlk;
     uint8_t *tree, *treeR;
     int64_t treeCap;
@@ -1066,24 +1082,37 @@ __device__ __forceinline__ void str_put(Str128 &s, uint32_t bits, int ntok)
 
 struct Quad { Str128 s; int preDs, aliveAtDs, maxErr; uint32_t l1; };
 
+// inner: codes of the block's internal nodes at depths D-10 .. D-3, heap-ordered (node (l, i) at (1<<l)+i)
 __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ Tb,
-                                   const uint8_t *__restrict__ Rl, int D, int maxDepth, int tol, const uint8_t *dmap,
-                                   int Ds, uint32_t r0)
+                                   const uint8_t *__restrict__ Rl, const uint8_t *inner, bool rootLive,
+                                   unsigned long long upSpine, int D, int maxDepth, int tol, int Ds, uint32_t r0)
 {
     Quad Q;
     Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0; Q.maxErr = 0; Q.l1 = 0;
-    const int jmin = r0 ? D - (__ffs((int)r0) - 1) : 0;          // <= D-2
-    // every load is issued before any is looked at: one memory latency instead of a dependent chain
-    const int parentCode = jmin > 0 ? Cb[((int64_t)1 << (jmin - 1)) + (r0 >> (D - jmin + 1))] : 0;
+    const uint32_t lr = r0 & 1023u;                                  // rank inside the block
+    // every global load is issued before any is looked at: one memory latency, no dependent chain
     const int quadCode = Cb[((int64_t)1 << (D - 2)) + (r0 >> 2)];
     const uint32_t pair = *(const uint16_t *)(Cb + ((int64_t)1 << (D - 1)) + (r0 >> 1));
     const uint32_t cl = *(const uint32_t *)(Cb + ((int64_t)1 << D) + r0);
     const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
     const uint32_t rl = *(const uint32_t *)(Rl + r0);
-    bool alive = parentCode != 3;
-    for (int j = jmin; alive && j <= D - 2; ++j) {                 // spine down to the quad's depth-(D-2) node
+    bool alive;
+    int j;
+    if (lr == 0) {                            // first rank of the block: the spine above depth D-10 comes precomputed
+        const int nsp = (int)(upSpine >> 56);
+        if (nsp) { Q.s.lo = upSpine & 0x00FFFFFFFFFFFFFFull; Q.s.n = nsp; }
+        alive = rootLive;
+        j = D - 10;
+    } else {
+        const int c0 = __ffs((int)lr) - 1;    // 2..9
+        j = D - c0;                           // first spine depth (> D-10)
+        const int l = j - 1 - (D - 10);       // parent level inside the block
+        alive = inner[(1 << l) + (lr >> (D - j + 1))] != 3;
+    }
+    for (; alive && j <= D - 2; ++j) {         // spine down to the quad's depth-(D-2) node
         if (j == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
-        const int code = j == D - 2 ? quadCode : Cb[((int64_t)1 << j) + (r0 >> (D - j))];
+        const int l = j - (D - 10);
+        const int code = j == D - 2 ? quadCode : inner[(1 << l) + (lr >> (D - j))];
         str_put(Q.s, (uint32_t)code, 1);
         if (code == 3) alive = false;
     }
@@ -1137,16 +1166,29 @@ k_block_alive(EmitArgs a, int64_t nblk)
     const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blk >= nblk) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *dmap = a.ctrls[brick].distanceMap;
     const int dl = a.D - 10;
     bool alive = true;
+    int val = dmap[0];                       // decoded scalar along the path (root: R.cpp:743)
+    unsigned long long spine = 0;            // tokens above depth D-10 owned by the block's first rank
+    int nsp = 0;
+    const uint32_t r0 = (uint32_t)blk << 10;
+    const int jmin = r0 ? a.D - (__ffs((int)r0) - 1) : 0;     // first spine depth of rank r0 (<= dl)
+    bool pathAlive = true;
     for (int j = 0; j < dl; ++j) {
-        if (Cb[((int64_t)1 << j) + (blk >> (dl - j))] == 3) {
+        const int code = Cb[((int64_t)1 << j) + (blk >> (dl - j))];
+        if (j > 0) val = apply_code(val, code, dmap[j]);
+        if (pathAlive && j >= jmin) { spine |= (unsigned long long)code << (2 * nsp); ++nsp; }
+        if (code == 3 && pathAlive) {
             // first pruned node on the path: it is emitted itself, by the block holding ITS first leaf
             alive = ((blk >> (dl - j)) << (dl - j)) == blk;
-            break;
+            pathAlive = false;
         }
     }
-    a.blockAlive[(int64_t)brick * a.nEmitBlk + blk] = alive ? 1 : 0;
+    const int64_t o = (int64_t)brick * a.nEmitBlk + blk;
+    a.blockAlive[o] = (uint8_t)((alive ? 1 : 0) | (pathAlive ? 2 : 0));   // bit1: the depth-(D-10) node itself is live
+    a.blockVal[o] = (uint8_t)val;            // scalar of the depth-(D-11) parent (codes applied down to depth dl-1)
+    a.blockSpine[o] = spine | ((unsigned long long)nsp << 56);
 }
 
 template <bool WRITE>
@@ -1162,20 +1204,29 @@ k_emit4(EmitArgs a)
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
     const uint32_t r0 = blockIdx.x * EMIT4_RANKS + threadIdx.x * 4;
-    if (!a.blockAlive[(int64_t)brick * a.nEmitBlk + blockIdx.x]) {          // wave-uniform: nothing to emit here
-        if (!WRITE) { if (threadIdx.x == 0) a.blockTot[(int64_t)brick * a.nEmitBlk + blockIdx.x] = 0; return; }
-        if (threadIdx.x == 0) a.blockL1[(int64_t)brick * a.nEmitBlk + blockIdx.x] = 0;
+    __shared__ uint8_t inner[256];
+    const int64_t bo = (int64_t)brick * a.nEmitBlk + blockIdx.x;
+    const int bflags = a.blockAlive[bo];
+    const int bval = a.blockVal[bo];
+    const unsigned long long upSpine = a.blockSpine[bo];
+    if (!(bflags & 1)) {          // wave-uniform: nothing to emit here
+        if (!WRITE) { if (threadIdx.x == 0) a.blockTot[bo] = 0; return; }
+        if (threadIdx.x == 0) a.blockL1[bo] = 0;
         if ((r0 & ((1u << a.K) - 1u)) == 0) {     // index entries of a dead region: value of the pruned ancestor
-            const uint32_t sidx = r0 >> a.K;
-            int val = c.distanceMap[0];
-            for (int j = 1; j <= a.Ds; ++j) val = apply_code(val, Cb[((int64_t)1 << j) + (sidx >> (a.Ds - j))], c.distanceMap[j]);
-            a.idxOff[(int64_t)brick * a.nIdx + sidx] = VR_IDX_DEAD;
-            a.idxVal[(int64_t)brick * a.nIdx + sidx] = (uint8_t)val;
+            a.idxOff[(int64_t)brick * a.nIdx + (r0 >> a.K)] = VR_IDX_DEAD;
+            a.idxVal[(int64_t)brick * a.nIdx + (r0 >> a.K)] = (uint8_t)bval;   // codes below a pruned node are all 3
         }
         return;
     }
+    // the block's internal nodes of depths D-10 .. D-3 (255 codes) into LDS, one per thread
+    if (threadIdx.x >= 1) {
+        const int t = threadIdx.x;                    // heap index inside the block: 1 .. 255
+        const int l = 31 - __clz(t);
+        inner[t] = Cb[((int64_t)1 << (a.D - 10 + l)) + (((int64_t)blockIdx.x) << l) + (t - (1 << l))];
+    }
     if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
-    const Quad Q = quad_tokens(Cb, Tb, Rl, a.D, a.maxDepth, a.tol, c.distanceMap, a.Ds, r0);
+    __syncthreads();
+    const Quad Q = quad_tokens(Cb, Tb, Rl, inner, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.tol, a.Ds, r0);
     uint32_t tot;
     const uint32_t lo = block_excl_scan_u32((uint32_t)Q.s.n, shw, tot);
     if (!WRITE) {
@@ -1199,10 +1250,17 @@ k_emit4(EmitArgs a)
         if (nbits > 96) atomicOr(&W[w + 3], (uint32_t)(v1 >> 32));
         if (nbits > 128) atomicOr(&W[w + 4], v2);
     }
-    if ((r0 & ((1u << a.K) - 1u)) == 0) {     // decode side-car index entry (K >= 2)
+    if ((r0 & ((1u << a.K) - 1u)) == 0) {     // decode side-car index entry (K >= 2): depth Ds = D-K >= D-10
         const uint32_t sidx = r0 >> a.K;
-        int val = c.distanceMap[0];
-        for (int j = 1; j <= a.Ds; ++j) val = apply_code(val, Cb[((int64_t)1 << j) + (sidx >> (a.Ds - j))], c.distanceMap[j]);
+        int val = bval;                        // scalar of the parent of the block's depth-(D-10) node
+        const uint32_t lr = r0 & 1023u;
+        for (int j = a.D - 10; j <= a.Ds; ++j) {
+            const int l = j - (a.D - 10);
+            const int code = j == a.D - 2 ? Cb[((int64_t)1 << j) + (r0 >> 2)]
+                           : (j == a.D - 1 ? Cb[((int64_t)1 << j) + (r0 >> 1)]
+                           : (j == a.D ? Cb[((int64_t)1 << j) + r0] : inner[(1 << l) + (lr >> (a.D - j))]));
+            val = j == 0 ? val : apply_code(val, code, c.distanceMap[j]);
+        }
         a.idxOff[(int64_t)brick * a.nIdx + sidx] = Q.aliveAtDs ? g0 + lo + (uint32_t)Q.preDs : VR_IDX_DEAD;
         a.idxVal[(int64_t)brick * a.nIdx + sidx] = (uint8_t)val;
     }
@@ -1379,7 +1437,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
     a.blockL1 = bs->blockL1;
-    a.blockAlive = bs->blockAlive;
+    a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
     const bool quad = !mr && D >= 12 && bs->K >= 2;
