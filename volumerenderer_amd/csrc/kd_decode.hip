@@ -168,6 +168,7 @@ k_decode_tile(TileArgs a)
     __shared__ uint32_t strS[DEC_WAVES][DEC_SW * 64];   // [word][lane]
     __shared__ uint8_t stkS[DEC_WAVES][8 * 64];         // [level][lane]
     __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
+    __shared__ uint32_t lutS[128];   // token-step action table (built below from dmS)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * DEC_WAVES + wave;
@@ -180,6 +181,34 @@ k_decode_tile(TileArgs a)
         const int t = threadIdx.x;
         // [0] = 0: the subtree root keeps the value stored in the index
         dmS[t] = t == 0 ? 0 : (t < 8 ? dmap[a.Ds + (t < 7 ? t : 0)] : dmap[a.D + (t - 8)]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        // action table: rows 0..6 tree level j, row 8 = branch exhausted, rows 9..15 = branch step 1..7
+        const int key = threadIdx.x, row = key >> 3, tok = (key >> 1) & 3, nxt3 = key & 1;
+        int delta = 0, usedx = 2, term = 0, desc = 0, nchain = 0, count = 1;
+        if (row < 8) {
+            const int j = row;
+            const bool is3 = tok == 3, lf = !is3 && j == 6;
+            desc = (!is3 && j < 6) ? 1 : 0;
+            term = (is3 || (lf && nxt3)) ? 1 : 0;
+            usedx = (lf && nxt3) ? 4 : 2;
+            nchain = (lf && !nxt3) ? 1 : 0;
+            count = is3 ? (64 >> (j > 6 ? 6 : j)) : 1;
+            const int dist = dmS[j > 6 ? 0 : j];
+            delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+        } else {
+            const int cidx = row - 8;                 // 0: exhausted
+            const bool exhausted = cidx == 0, is3 = !exhausted && tok == 3, last = !exhausted && cidx >= VR_CHAIN_LEVELS;
+            term = (exhausted || is3 || last || nxt3) ? 1 : 0;
+            usedx = exhausted ? 0 : 2 + ((!is3 && !last && nxt3) ? 2 : 0);
+            nchain = term ? 0 : cidx + 1;
+            const int dist = dmS[8 + cidx];
+            delta = (exhausted || is3) ? 0 : (tok == 1 ? dist : (tok == 2 ? -dist : 0));
+        }
+        const int single = (term && count == 1) ? 1 : 0, fillc = (term && count > 1) ? count : 0;
+        lutS[key] = (uint32_t)(delta + 256) | ((uint32_t)(usedx >> 1) << 10) | ((uint32_t)term << 12) | ((uint32_t)desc << 13) |
+                    ((uint32_t)nchain << 14) | ((uint32_t)fillc << 20) | ((uint32_t)single << 27);
     }
     __syncthreads();
     if (!tileValid) return;
@@ -214,9 +243,11 @@ k_decode_tile(TileArgs a)
 #pragma unroll
             for (int k = 0; k < DEC_SW; ++k) str[k * 64 + lane] = W[wbase + k];
             __builtin_amdgcn_s_waitcnt(0xC07F);
-            // ---- walk while somebody can still look ahead.  The body is branch-free per lane
-            // (selects + LDS writes steered to a scratch row): divergent branches here cost more
-            // scalar exec-mask instructions than the vector work they skip.
+            // ---- walk while somebody can still look ahead.  The body is branch-free per lane:
+            // everything a token step decides (signed value delta, bits consumed, terminal?,
+            // descend?, next branch step, fill size) comes packed from a 128-entry LDS table
+            // keyed by (mode, level or branch step, code, "terminator follows"), so the per-lane
+            // booleans never reach the scalar unit as exec-mask algebra.
             while (true) {
                 const bool act = !done && (bitpos >> 5) < DEC_SW - 2;
                 if (__ballot(act) == 0ull) break;
@@ -230,44 +261,37 @@ k_decode_tile(TileArgs a)
                     leaf += n4; fill -= n4;
                     done = done || (filling && fill == 0 && p == 0x80000000u);
                 }
-                const bool tk = act && !filling;            // this lane consumes tokens now
+                const uint32_t tk = (act && !filling) ? 1u : 0u;   // this lane consumes tokens now
                 const uint32_t k = bitpos >> 5;
                 const uint32_t w0 = str[k * 64 + lane], w1 = str[(k + 1) * 64 + lane];
                 const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);   // 16 tokens ahead
-                const bool tree = chain == 0;
-                // tree token at depth j
-                const int j = (31 - __clz((int)p)) & 7;
-                // grown branch: steps chain..7 of the same voxel (distances 64..1): skip "keep" codes
-                const int rem = 8 - chain;
-                const int z = (__ffs((int)(x | (1u << (2 * rem)))) - 1) >> 1;
-                const int c2 = chain + z;                       // step of the first non-keep token
-                const bool exhausted = !tree && z >= rem;       // only keeps up to depth D+7
-                const int tok = (int)((tree ? x : (x >> (2 * z))) & 3u);
-                const int dist = dmS[tree ? j : 8 + (c2 < 7 ? c2 : 7)];
-                const int sv = stk[((j + 7) & 7) * 64 + lane];
-                const int nv = clamp_add(tree ? sv : v, exhausted ? 0 : tok, dist);
-                const bool is3 = tok == 3 && !exhausted;
-                const bool desc = tree && !is3 && j < 6;
-                const bool lf = tree && !is3 && j == 6;
-                const int sh = tree ? 2 : 2 * z + 2;
-                const bool nxt3 = ((x >> sh) & 3u) == 3u;       // a terminator follows: swallow it
-                const bool last = !tree && c2 >= VR_CHAIN_LEVELS;
-                const bool term = tree ? (is3 || (lf && nxt3)) : (exhausted || is3 || last || nxt3);
-                const int used = tree ? ((lf && nxt3) ? 4 : 2)
-                                      : (exhausted ? 2 * rem : 2 * z + 2 + ((!is3 && !last && nxt3) ? 2 : 0));
-                const int nchain = tree ? ((lf && !nxt3) ? 1 : 0) : (term ? 0 : c2 + 1);
-                const int count = (tree && is3) ? (64 >> j) : 1;
-                // commit
+                const uint32_t tree = chain == 0 ? 1u : 0u;
+                const uint32_t j = (31u - (uint32_t)__clz((int)p)) & 7u;
+                // grown branch: skip the run of "keep" codes (sentinel bit stops the count at the branch end)
+                const uint32_t rem = 8u - (uint32_t)chain;
+                const uint32_t zr = (uint32_t)(__ffs((int)(x | (1u << (2u * rem)))) - 1) >> 1;
+                const uint32_t z = tree ? 0u : zr;
+                const uint32_t exhausted = (!tree && zr == rem) ? 1u : 0u;     // only keeps up to depth D+7
+                const uint32_t xs = x >> (2u * z);
+                const uint32_t tok = xs & 3u;
+                const uint32_t n3 = ((xs >> 2) & 3u) == 3u ? 1u : 0u;           // a terminator follows
+                const uint32_t row = tree ? j : (exhausted ? 8u : 8u + (uint32_t)chain + z);
+                const uint32_t e = lutS[row * 8u + (exhausted ? 0u : tok * 2u + n3)];
+                const int sv = stk[((j + 7u) & 7u) * 64 + lane];
+                int nv = (tree ? sv : v) + (int)(e & 1023u) - 256;
+                nv = nv < 0 ? 0 : (nv > 255 ? 255 : nv);                        // decoder step R.cpp:783-787
+                const uint32_t desc = (e >> 13) & tk;
+                const uint32_t t = (e >> 12) & tk;
+                const uint32_t single = (e >> 27) & tk;
+                const uint32_t fillc = (e >> 20) & 127u;
                 v = tk ? nv : v;
-                stk[((tk && desc) ? j : 6) * 64 + lane] = (uint8_t)nv;
-                p = (tk && desc) ? (p << 1) : p;
-                chain = tk ? nchain : chain;
-                bitpos += tk ? (uint32_t)used : 0u;
-                const bool t = tk && term;
-                const bool single = t && count == 1;
+                stk[(desc ? j : 6u) * 64 + lane] = (uint8_t)nv;
+                p <<= desc;
+                chain = tk ? (int)((e >> 14) & 7u) : chain;
+                bitpos += tk ? 2u * z + ((e >> 10) & 3u) * 2u : 0u;
                 tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)nv;
-                leaf += single ? 1 : 0;
-                fill = (t && count > 1) ? count : fill;
+                leaf += (int)single;
+                fill = (t && fillc) ? (int)fillc : fill;
                 uint32_t np = p + 1u;
                 np >>= (__ffs((int)np) - 1);
                 const bool parked = t && np == 1u;              // no further tokens are mine
