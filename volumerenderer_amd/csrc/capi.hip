@@ -260,6 +260,7 @@ vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
     vr_status rc = sync_ctrl(b);
     if (rc != VR_OK) return rc;
     const Ctrl &c = b.hostCtrl[brick];
+    if (c.emitOverflow) return VR_ERR_STATE;   // internal count/emit mismatch: no valid stream
     memset(info, 0, sizeof(*info));
     info->X = b.g.X; info->Y = b.g.Y; info->Z = b.g.Z;
     info->orig_tree_depth = b.D;

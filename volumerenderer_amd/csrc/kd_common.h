@@ -59,6 +59,7 @@ struct Ctrl {
     int32_t estFallbacks;    // segments the estimator had to walk node by node (diagnostic)
     int32_t estSeg;          // estimator: next segment to verify
     int32_t estDone;         // estimator: level finished
+    int32_t emitOverflow;    // emit refused to write past the stream buffer (internal error)
     uint8_t distanceMap[VR_MAX_DEPTH + 8];
 };
 

@@ -17,6 +17,8 @@
 //                            and grown chain
 #include "brickset.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace vr {
 
@@ -175,7 +177,7 @@ __global__ void k_ctrl_init(Ctrl *ctrls)
     c.cur = 0; c.prev = 1; c.pendingEqual = 0;
     c.par = 0; c.ra = 1; c.rb = 2;
     c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0;
-    c.estS = 0; c.estC = 0; c.estTbase = 0; c.estFallbacks = 0; c.estSeg = 0; c.estDone = 0;
+    c.estS = 0; c.estC = 0; c.estTbase = 0; c.estFallbacks = 0; c.estSeg = 0; c.estDone = 0; c.emitOverflow = 0;
     for (int i = 0; i < VR_MAX_DEPTH + 8; ++i) c.distanceMap[i] = 0;
 }
 
@@ -720,9 +722,11 @@ k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRan
 // depends on its two children.
 __global__ void __launch_bounds__(256)
 k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
-          uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride)
+          uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride, int maxDepth,
+          uint32_t *__restrict__ subTok, int64_t nEmitBlk)
 {
     __shared__ uint8_t fl[2][2048];
+    __shared__ uint16_t cnt[2][2048];      // tokens a (live) subtree emits, carried upwards with the flags
     __shared__ uint8_t lv[2048], lvOld[2048];     // codes of the block's nodes at depths D-12 .. D-2, heap order
     const int brick = blockIdx.y, t = threadIdx.x;
     Ctrl &c = ctrls[brick];
@@ -743,6 +747,7 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
     int maxErr = 0;
     uint32_t pr = 0;            // pruned flags of my 16 leaves
+    uint8_t tl[16];             // tokens of my 16 leaves
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int sh = (k & 3) * 8;
@@ -753,6 +758,17 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
             cw[k >> 2] |= 3u << sh;
             pr |= 1u << k;
         } else if (code == 3) pr |= 1u << k;
+        // tokens this leaf emits when live: its code, then the grown branch (R.cpp:655-704)
+        int nt = 1;
+        if (subTok && !((pr >> k) & 1u)) {
+            int r2 = rec, depth = D;
+            while (depth < maxDepth) {
+                const int e2 = r2 > tt ? r2 - tt : tt - r2;
+                if (e2 > tol) { ++depth; r2 = encode_node(tt, r2, 64 >> (depth - D - 1)).recon; ++nt; }
+                else { ++nt; break; }
+            }
+        }
+        tl[k] = (uint8_t)nt;
     }
     *(uint4 *)(Cb + li) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
     if (CR) {
@@ -774,7 +790,9 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
             const int code = (int)((v >> (8 * k)) & 255ull);
             const bool p = both && code == 0;
             if (p) { v |= 3ull << (8 * k); vr |= 3ull << (8 * k); }
-            fl[1][t * 8 + k] = (uint8_t)((p || code == 3) ? 1 : 0);
+            const bool f3 = p || code == 3;
+            fl[1][t * 8 + k] = (uint8_t)(f3 ? 1 : 0);
+            cnt[1][t * 8 + k] = (uint16_t)(f3 ? 1 : 1 + tl[2 * k] + tl[2 * k + 1]);
         }
         *(unsigned long long *)(Cb + ni) = v;
         if (CR) *(unsigned long long *)(CR + ni) = vr;
@@ -790,7 +808,11 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
             const int code = lv[hb + i];
             const bool p = both && code == 0;
             if (p) lv[hb + i] = 3;
-            fl[dst][i] = (uint8_t)((p || code == 3) ? 1 : 0);
+            const bool f3 = p || code == 3;
+            fl[dst][i] = (uint8_t)(f3 ? 1 : 0);
+            const uint32_t cn = f3 ? 1u : 1u + cnt[src][2 * i] + cnt[src][2 * i + 1];
+            cnt[dst][i] = (uint16_t)cn;
+            if (l == 10 && subTok) subTok[(int64_t)brick * nEmitBlk + (size_t)blockIdx.x * 4 + i] = cn;   // one emit block
         }
         __syncthreads();
     }
@@ -1189,6 +1211,9 @@ k_block_alive(EmitArgs a, int64_t nblk)
     a.blockAlive[o] = (uint8_t)((alive ? 1 : 0) | (pathAlive ? 2 : 0));   // bit1: the depth-(D-10) node itself is live
     a.blockVal[o] = (uint8_t)val;            // scalar of the depth-(D-11) parent (codes applied down to depth dl-1)
     a.blockSpine[o] = spine | ((unsigned long long)nsp << 56);
+    // tokens this block emits: the upper spine its first rank owns + its own subtree if that is live
+    // (k_prune12 left the subtree's count in blockOff[], which k_emit_scan overwrites afterwards)
+    a.blockTot[o] = (uint32_t)nsp + (pathAlive ? a.blockOff[o] : 0u);
 }
 
 template <bool WRITE>
@@ -1235,6 +1260,12 @@ k_emit4(EmitArgs a)
     }
     const uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blockIdx.x];
     const uint32_t phase = g0 & 15u;
+    // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
+    // would be a bug; it must surface as a failed parity check, not as a memory fault)
+    if (((unsigned long long)g0 + tot + 32ull) * 2ull > (unsigned long long)a.treeCap * 8ull) {
+        if (threadIdx.x == 0) atomicMax(&c.emitOverflow, 1);
+        return;
+    }
     if (Q.s.n) {
         const uint32_t pos = phase + lo;
         const int sh = (int)(pos & 15u) * 2;
@@ -1347,6 +1378,16 @@ __global__ void k_fix_chain_distances(int D, int maxDepth, Ctrl *ctrls, Ctrl *ct
     }
 }
 
+// VRHIP_SYNC=1: synchronise after every phase and report the first failing one (debug aid)
+static bool dbg_sync(hipStream_t st, const char *phase)
+{
+    static const bool on = getenv("VRHIP_SYNC") != nullptr;
+    if (!on) return true;
+    hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "[vrhip] phase %s: %s\n", phase, hipGetErrorString(e));
+    return e == hipSuccess;
+}
+
 int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
 {
     const int D = bs->D, B = bs->B;
@@ -1404,10 +1445,12 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         }
     }
     hipEventRecord(bs->ev[1], st);
+    dbg_sync(st, "pyramid");
     // ---- COMPRESS
     compress_stream(bs, bs->mid, st);
     if (mr) compress_stream(bs, bs->rng, st);
     hipEventRecord(bs->ev[2], st);
+    dbg_sync(st, "compress");
     // ---- PRUNE
     ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
@@ -1415,7 +1458,8 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     if (D >= 12) {
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
-                           bs->leafStride);
+                           bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
+                           bs->nEmitBlk);   // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
@@ -1427,6 +1471,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_fix_chain_distances, dim3(B), dim3(64), 0, st, D, bs->maxDepth, bs->mid.ctrl,
                        mr ? bs->rng.ctrl : nullptr);
     hipEventRecord(bs->ev[3], st);
+    dbg_sync(st, "prune");
     // ---- CONVERT
     EmitArgs a;
     a.codes = bs->mid.codes; a.codesR = mr ? bs->rng.codes : nullptr;
@@ -1442,17 +1487,17 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
     const bool quad = !mr && D >= 12 && bs->K >= 2;
     const int64_t nblk = cdiv((int64_t)1 << D, quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK);
-    if (quad) {
-        hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-        hipLaunchKernelGGL(k_emit4<false>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
-    }
+    if (quad) hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);   // + token counts
     else hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
+    dbg_sync(st, "block_alive/count");
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
+    dbg_sync(st, "emit_scan");
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
     if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, nblk);
     hipEventRecord(bs->ev[4], st);
+    dbg_sync(st, "emit_write");
     return launch_status("encode");
 }
 
