@@ -163,3 +163,38 @@ def test_full_brick_256(vr, oracle, gen):
         assert "%016x" % oracle.fnv1a64(bs.decode().cpu().numpy()) == "e97ae40e1e4bb47c"
     if gen == "sphere_n0":
         assert bs.info(0)["num_active_nodes"] == 21373869
+
+
+def test_config3_error_tolerance_sweep(vr, oracle):
+    """BASELINE config 3 shape (2x2x2 grid of bricks, one tree per brick, tolerance sweep): the DECODED
+    max/mean error (vr_measure_error on levelCut output) and the encoder's self-reported leaf error are
+    reported separately and both equal the oracle's (they differ when a revert happened, defect C-2)."""
+    import torch
+    n = 64
+    rng = np.random.default_rng(9)
+    bricks = []
+    for b in range(8):
+        base = oracle.gen_sphere(n, 7 if b % 2 else 3, seed=12345 + b).astype(np.int32)
+        bricks.append(np.clip(base + rng.integers(-b, b + 1, base.shape), 0, 255).astype(np.uint8))
+    vol = np.stack(bricks)
+    for tol in (0, 1, 2, 4, 6, 12):
+        bs = vr.BrickSet(8, (n, n, n), tol, 5)
+        bs.build(vol)
+        dec = bs.decode()
+        for b in range(8):
+            ref = oracle.OracleTree(bricks[b].copy(), tolerance=tol, max_epochs=5).build()
+            rdec = ref.levelCut()
+            got = dec[b * n ** 3:(b + 1) * n ** 3]
+            assert np.array_equal(got.cpu().numpy().reshape(n, n, n), rdec)
+            mx, mean = vr.measure_error(got, bricks[b])
+            assert mx == oracle.measure_max_error(rdec, bricks[b])
+            assert abs(mean - oracle.measure_mean_error(rdec, bricks[b])) < 1e-12
+            st = ref.leaf_stats()
+            info = bs.info(b)
+            assert info["max_error_after"] == st["max_after"]
+            assert abs(info["mean_l1_after"] - st["l1_after"]) < 1e-12
+            assert info["num_reverts"] == ref.numReverts
+            if ref.numReverts == 0:
+                assert mx <= max(tol, 0) or tol == 0 and mx == 0
+        err = vr.query_error(dec, vol).cpu().numpy()
+        assert err.max() == max(oracle.measure_max_error(dec[b * n ** 3:(b + 1) * n ** 3].cpu().numpy(), bricks[b]) for b in range(8))

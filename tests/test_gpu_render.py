@@ -189,3 +189,20 @@ def test_composite_slabs_kernel_matches_oracle(vr, oracle):
     lo, hi = 20 * w, 41 * w
     tile = D._gpu_combine(stack[:, lo:hi].contiguous(), lo, 2, cg, full).cpu().numpy()
     assert np.abs(tile - got[lo:hi]).max() <= 1e-6
+
+
+def test_config3_isosurface_of_brick_grid(vr, oracle):
+    """BASELINE config 3: 2x2x2 bricks assembled into one volume, iso-surface shader at several iso values."""
+    n = 32
+    bricks = np.stack([oracle.gen_sphere(n, 3, seed=100 + b) for b in range(8)])
+    bmap = vr.fill_volume_brick_map(2, 2, 2)
+    ijk = np.array([bmap[b] for b in range(8)], np.int64)
+    vol = vr.assemble_bricks(bricks, (n, n, n), ijk, (2, 2, 2))
+    host = vol.cpu().numpy().reshape(2 * n, 2 * n, 2 * n)
+    for iso in (40 / 255.0, 80 / 255.0, 120 / 255.0):
+        cg, co = _cams(vr, oracle, (0.2, 0.3, -0.9), (-0.2, -0.3, 1.0))
+        Pg, Po = vr.default_params(120, 90, (256, 256, 128), 1, iso), oracle.default_params(120, 90, (256, 256, 128), 1, iso)
+        got = vr.raycast(vol, (2 * n, 2 * n, 2 * n), cg, Pg).cpu().numpy()
+        want = oracle.render(host, co, Po)
+        assert np.abs(got - want).max() <= TOL
+        assert (want[..., 0] < 0.99).any()

@@ -678,26 +678,49 @@ __global__ void k_level_end(int d, Ctrl *ctrls)
 // ------------------------------------------------------------------ prune ----
 __global__ void __launch_bounds__(256)
 k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
-             uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride)
+             uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride, int maxDepth,
+             unsigned long long *__restrict__ blockL1, int64_t nEmitBlk)
 {
+    __shared__ unsigned long long shl[4];
     const int brick = blockIdx.y;
     Ctrl &c = ctrls[brick];
     const uint32_t n = 1u << D;
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    int err = 0;
+    int err = 0, fe = 0;
     if (r < n) {
         const int64_t hi = (int64_t)brick * heapStride + ((int64_t)1 << D) + r;
         int t = temp[hi];
         int rec = rb.b[c.par][(int64_t)brick * leafStride + r];
         err = rec > t ? rec - t : t - rec;
+        fe = err;
         if (codes[hi] == 0 && err < tol) {   // R.cpp:618-626 (leaf: no children)
             codes[hi] = 3;
             if (codesRange) codesRange[hi] = 3;
+        } else if (codes[hi] != 3) {         // an unpruned leaf is always live: its error after branch growth
+            int depth = D;
+            while (depth < maxDepth) {
+                const int e2 = rec > t ? rec - t : t - rec;
+                if (e2 > tol) { ++depth; rec = encode_node(t, rec, 64 >> (depth - D - 1)).recon; }
+                else break;
+            }
+            fe = rec > t ? rec - t : t - rec;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(err, o); err = u > err ? u : err; }
+    int fm = fe;
+    unsigned long long l1 = (unsigned long long)fe;
+    for (int o = 32; o > 0; o >>= 1) {
+        int u = __shfl_xor(err, o); err = u > err ? u : err;
+        int w = __shfl_xor(fm, o); fm = w > fm ? w : fm;
+        l1 += __shfl_xor(l1, o);
+    }
     // one contended atomic per wave would serialise the whole grid: only waves that raise the max try
-    if ((threadIdx.x & 63) == 0 && err > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, err); // R.cpp:71-76
+    if ((threadIdx.x & 63) == 0) {
+        if (err > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, err); // R.cpp:71-76
+        if (fm > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, fm);     // R.cpp:115-120
+        shl[threadIdx.x >> 6] = l1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) blockL1[(int64_t)brick * nEmitBlk + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
 }
 
 __global__ void __launch_bounds__(256)
@@ -723,7 +746,7 @@ k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRan
 __global__ void __launch_bounds__(256)
 k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
           uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride, int maxDepth,
-          uint32_t *__restrict__ subTok, int64_t nEmitBlk)
+          uint32_t *__restrict__ subTok, int64_t nEmitBlk, unsigned long long *__restrict__ blockL1)
 {
     __shared__ uint8_t fl[2][2048];
     __shared__ uint16_t cnt[2][2048];      // tokens a (live) subtree emits, carried upwards with the flags
@@ -748,6 +771,8 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     int maxErr = 0;
     uint32_t pr = 0;            // pruned flags of my 16 leaves
     uint8_t tl[16];             // tokens of my 16 leaves
+    int maxAfter = 0;
+    uint32_t l1After = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int sh = (k & 3) * 8;
@@ -759,16 +784,19 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
             pr |= 1u << k;
         } else if (code == 3) pr |= 1u << k;
         // tokens this leaf emits when live: its code, then the grown branch (R.cpp:655-704)
-        int nt = 1;
-        if (subTok && !((pr >> k) & 1u)) {
+        int nt = 1, fe = err;
+        if (!((pr >> k) & 1u)) {            // an unpruned leaf is always live (pruning is closed downwards)
             int r2 = rec, depth = D;
             while (depth < maxDepth) {
                 const int e2 = r2 > tt ? r2 - tt : tt - r2;
                 if (e2 > tol) { ++depth; r2 = encode_node(tt, r2, 64 >> (depth - D - 1)).recon; ++nt; }
                 else { ++nt; break; }
             }
+            fe = r2 > tt ? r2 - tt : tt - r2;
         }
         tl[k] = (uint8_t)nt;
+        maxAfter = fe > maxAfter ? fe : maxAfter;     // encoder's own statistics after branch growth,
+        l1After += (uint32_t)fe;                      // over every leaf (R.cpp:115-129)
     }
     *(uint4 *)(Cb + li) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
     if (CR) {
@@ -778,8 +806,17 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         for (int k = 0; k < 16; ++k) if ((pr >> k) & 1u) qw[k >> 2] |= 3u << ((k & 3) * 8);   // M.cpp:864-865
         *(uint4 *)(CR + li) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
     }
-    for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(maxErr, o); maxErr = u > maxErr ? u : maxErr; }
-    if ((t & 63) == 0 && maxErr > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, maxErr);
+    unsigned long long l1w = l1After;
+    for (int o = 32; o > 0; o >>= 1) {
+        int u = __shfl_xor(maxErr, o); maxErr = u > maxErr ? u : maxErr;
+        int w = __shfl_xor(maxAfter, o); maxAfter = w > maxAfter ? w : maxAfter;
+        l1w += __shfl_xor(l1w, o);
+    }
+    if ((t & 63) == 0) {
+        if (maxErr > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, maxErr);
+        if (maxAfter > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, maxAfter);
+        if (blockL1) blockL1[(int64_t)brick * nEmitBlk + (size_t)blockIdx.x * 4 + (t >> 6)] = l1w;   // one wave = 1024 leaves
+    }
     // level D-1: 8 nodes per thread, children flags in registers
     {
         const int64_t ni = ((int64_t)1 << (D - 1)) + (base >> 1) + t * 8;
@@ -1020,7 +1057,6 @@ k_emit_write(EmitArgs a)
 {
     __shared__ uint32_t shw[4];
     __shared__ uint32_t W[EMIT_LDS_WORDS], WR[EMIT_LDS_WORDS];
-    __shared__ unsigned long long shl1[4];
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
     const bool mr = a.codesR != nullptr;
@@ -1063,16 +1099,7 @@ k_emit_write(EmitArgs a)
         a.idxOff[(int64_t)brick * a.nIdx + s] = o.aliveAtDs ? g0 + lo + (uint32_t)o.preDs : VR_IDX_DEAD;
         a.idxVal[(int64_t)brick * a.nIdx + s] = (uint8_t)val;
     }
-    // encoder's own statistics after branch growth (R.cpp:115-129)
-    int fe = o.finalErr > 0 ? o.finalErr : 0;
-    unsigned long long l1 = (unsigned long long)fe;
-    for (int q = 32; q > 0; q >>= 1) { int u = __shfl_xor(fe, q); fe = u > fe ? u : fe; l1 += __shfl_xor(l1, q); }
-    if ((threadIdx.x & 63) == 0) {
-        if (fe > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, fe);
-        shl1[threadIdx.x >> 6] = l1;
-    }
     __syncthreads();
-    if (threadIdx.x == 0) a.blockL1[(int64_t)brick * a.nEmitBlk + blockIdx.x] = shl1[0] + shl1[1] + shl1[2] + shl1[3];
     if (tot == 0) return;
     uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
     uint32_t *GR = mr ? (uint32_t *)(a.treeR + (int64_t)brick * a.treeCap) + (g0 >> 4) : nullptr;
@@ -1222,7 +1249,6 @@ k_emit4(EmitArgs a)
 {
     __shared__ uint32_t shw[4];
     __shared__ uint32_t W[WRITE ? EMIT4_LDS_WORDS : 1];
-    __shared__ unsigned long long shl1[4];
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
     const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
@@ -1236,7 +1262,6 @@ k_emit4(EmitArgs a)
     const unsigned long long upSpine = a.blockSpine[bo];
     if (!(bflags & 1)) {          // wave-uniform: nothing to emit here
         if (!WRITE) { if (threadIdx.x == 0) a.blockTot[bo] = 0; return; }
-        if (threadIdx.x == 0) a.blockL1[bo] = 0;
         if ((r0 & ((1u << a.K) - 1u)) == 0) {     // index entries of a dead region: value of the pruned ancestor
             a.idxOff[(int64_t)brick * a.nIdx + (r0 >> a.K)] = VR_IDX_DEAD;
             a.idxVal[(int64_t)brick * a.nIdx + (r0 >> a.K)] = (uint8_t)bval;   // codes below a pruned node are all 3
@@ -1295,15 +1320,7 @@ k_emit4(EmitArgs a)
         a.idxOff[(int64_t)brick * a.nIdx + sidx] = Q.aliveAtDs ? g0 + lo + (uint32_t)Q.preDs : VR_IDX_DEAD;
         a.idxVal[(int64_t)brick * a.nIdx + sidx] = (uint8_t)val;
     }
-    int fe = Q.maxErr;
-    unsigned long long l1 = Q.l1;
-    for (int q = 32; q > 0; q >>= 1) { int u = __shfl_xor(fe, q); fe = u > fe ? u : fe; l1 += __shfl_xor(l1, q); }
-    if ((threadIdx.x & 63) == 0) {
-        if (fe > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, fe);
-        shl1[threadIdx.x >> 6] = l1;
-    }
     __syncthreads();
-    if (threadIdx.x == 0) a.blockL1[(int64_t)brick * a.nEmitBlk + blockIdx.x] = shl1[0] + shl1[1] + shl1[2] + shl1[3];
     if (tot == 0) return;
     uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
     const uint32_t nw = ((phase + tot - 1) >> 4) + 1;
@@ -1459,12 +1476,13 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
                            bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
-                           bs->nEmitBlk);   // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
+                           bs->nEmitBlk,    // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
+                           (!mr && bs->K >= 2) ? bs->blockL1 : nullptr);
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
-                           bs->leafStride);
+                           bs->leafStride, bs->maxDepth, bs->blockL1, bs->nEmitBlk);
     for (int d = pruneFrom; d >= 0; --d)
         hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.codes,
                            mr ? bs->rng.codes : nullptr, bs->heapStride);
