@@ -117,9 +117,11 @@ vr_status vr_brickset_get_distance_map_range(vr_brickset *bs, int32_t brick, uin
 vr_status vr_brickset_get_packed4(vr_brickset *bs, int32_t brick, uint8_t *dst_host, int64_t capacity, int64_t *length);
 
 /* ---- decode: VolumeKdtree::levelCut (R.cpp:726-835) ----------------------------
- * out_dev: num_bricks * X*Y*Z bytes.  cut_depth must equal max_tree_depth (the only
- * depth at which the reference's walk is well defined) or be
- * < 0 (= max_tree_depth).  Asynchronous on `stream`. */
+ * out_dev: num_bricks * X*Y*Z bytes.  cut_depth == max_tree_depth (or < 0) is the reference's
+ * levelCut, bit-exact.  0 <= cut_depth < max_tree_depth is a PROGRESSIVE cut with defined
+ * semantics (new: the reference's walk de-synchronises there): the stream is
+ * parsed completely, refinement stops below the cut, every voxel gets the decoded scalar of its
+ * ancestor at depth min(cut_depth, depth of its terminal node).  Asynchronous on `stream`. */
 vr_status vr_brickset_decode(vr_brickset *bs, int32_t cut_depth, uint8_t *out_dev, void *stream);
 
 /* Install a foreign preorder stream (e.g. read from a reference-written file) as

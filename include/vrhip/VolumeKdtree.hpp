@@ -9,8 +9,10 @@
 //     std::vector<unsigned char> treeData; myTree->levelCut(myTree->maxTreeDepth, treeData); // :280-281
 //
 // Differences, all forced by reference defects: build() does not
-// empty the caller's vector (C-7: the error helpers need it); levelCut() accepts only
-// cutDepth == maxTreeDepth (C-4); open() of a missing file throws instead of exit(-1).
+// empty the caller's vector (C-7: the error helpers need it); levelCut() at cutDepth ==
+// maxTreeDepth is the reference's result, shallower cuts are a well-defined progressive decode
+// instead of the reference's de-synchronising walk (C-4); open() of a missing file throws
+// instead of exit(-1).
 #pragma once
 #include "../vrhip.h"
 #include <cstdint>

@@ -566,6 +566,75 @@ int vko_level_cut(const vko_tree *t, int cutDepth, byte *out)
     return rc;
 }
 
+/* NOT IN THE REFERENCE (its levelCut de-synchronises for cutDepth < maxTreeDepth, defect C-4):
+ * a well-defined progressive cut, used as the oracle of vr_brickset_decode(cut_depth < max).
+ * The stream is parsed completely (so subtrees below the cut are skipped correctly) but scalar
+ * updates stop below the cut: every voxel gets the decoded scalar of its ancestor at depth
+ * min(cutDepth, depth of its terminal node).  cutDepth == maxTreeDepth equals vko_level_cut. */
+int vko_level_cut_progressive(const vko_tree *t, int cutDepth, byte *out)
+{
+    if (t->numActiveNodes <= 0 || !t->tree) return -1;
+    lc_item *stack = (lc_item *)malloc(sizeof(lc_item) * (size_t)(t->maxTreeDepth + 8));
+    int sp = 0, rc = 0;
+    lc_item root;
+    root.idx = 0; root.depth = 0; root.scalar = t->distanceMap[0];
+    memcpy(root.mn, t->rootMin, sizeof root.mn);
+    memcpy(root.mx, t->rootMax, sizeof root.mx);
+    stack[sp++] = root;
+    while (sp > 0) {
+        lc_item cur = stack[sp - 1];
+        if (cur.idx >= t->numActiveNodes) { rc = -2; break; }
+        int code = tb_get(t->tree, cur.idx);
+        if (code == 3 || cur.depth == t->maxTreeDepth) {
+            for (int64_t x = cur.mn[0]; x < cur.mx[0]; x++)
+                for (int64_t y = cur.mn[1]; y < cur.mx[1]; y++)
+                    for (int64_t z = cur.mn[2]; z < cur.mx[2]; z++)
+                        out[get_cell(t, x, y, z)] = cur.scalar;
+            sp--;
+            int64_t nextRight = cur.idx + 1;
+            if (nextRight < t->numActiveNodes) {
+                if (sp == 0) { rc = -3; break; }
+                lc_item par = stack[--sp];
+                int c = tb_get(t->tree, nextRight);
+                byte scalar = par.scalar;
+                if (par.depth + 1 <= cutDepth) {
+                    if (c == 1) scalar = (byte)fmin(255.0, (double)scalar + (double)t->distanceMap[par.depth + 1]);
+                    else if (c == 2) scalar = (byte)fmax(0.0, (double)scalar - (double)t->distanceMap[par.depth + 1]);
+                }
+                int64_t ext[3] = { par.mx[0] - par.mn[0], par.mx[1] - par.mn[1], par.mx[2] - par.mn[2] };
+                if (ext[0] * ext[1] * ext[2] > 1) {
+                    int sd = par.depth % VKO_MAX_DIM, i = 0;
+                    while (ext[sd] == 1) sd = (par.depth + ++i) % VKO_MAX_DIM;
+                    par.mn[sd] = (par.mn[sd] + par.mx[sd]) / 2;
+                }
+                par.idx = nextRight; par.depth += 1; par.scalar = scalar;
+                stack[sp++] = par;
+            }
+        } else {
+            if (cur.depth >= t->origTreeDepth) sp--;
+            int64_t nextLeft = cur.idx + 1;
+            if (nextLeft >= t->numActiveNodes) { rc = -5; break; }
+            int c = tb_get(t->tree, nextLeft);
+            byte scalar = cur.scalar;
+            if (cur.depth + 1 <= cutDepth) {
+                if (c == 1) scalar = (byte)fmin(255.0, (double)scalar + (double)t->distanceMap[cur.depth + 1]);
+                else if (c == 2) scalar = (byte)fmax(0.0, (double)scalar - (double)t->distanceMap[cur.depth + 1]);
+            }
+            int64_t ext[3] = { cur.mx[0] - cur.mn[0], cur.mx[1] - cur.mn[1], cur.mx[2] - cur.mn[2] };
+            if (ext[0] * ext[1] * ext[2] > 1) {
+                int sd = cur.depth % VKO_MAX_DIM, i = 0;
+                while (ext[sd] == 1) sd = (cur.depth + ++i) % VKO_MAX_DIM;
+                cur.mx[sd] = (cur.mn[sd] + cur.mx[sd]) / 2;
+            }
+            cur.idx = nextLeft; cur.depth += 1; cur.scalar = scalar;
+            if (cur.depth > t->maxTreeDepth) { rc = -4; break; }
+            stack[sp++] = cur;
+        }
+    }
+    free(stack);
+    return rc;
+}
+
 /* R.cpp:386-411: error helpers.  The reference dereferences the (cleared)
  * input, C-7; here the original volume is passed explicitly. */
 int vko_measure_max_error(const byte *decoded, const byte *original, int64_t n)

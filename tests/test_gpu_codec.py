@@ -198,3 +198,32 @@ def test_config3_error_tolerance_sweep(vr, oracle):
                 assert mx <= max(tol, 0) or tol == 0 and mx == 0
         err = vr.query_error(dec, vol).cpu().numpy()
         assert err.max() == max(oracle.measure_max_error(dec[b * n ** 3:(b + 1) * n ** 3].cpu().numpy(), bricks[b]) for b in range(8))
+
+
+def test_progressive_cut_matches_oracle(vr, oracle, tmp_path):
+    """vr_brickset_decode(cut_depth < maxTreeDepth): defined progressive semantics (not the reference's
+    de-synchronising walk, C-4) against oracle.levelCutProgressive -- tile kernel (128^3), lane kernel
+    (32^3, 16x8x32) and a foreign stream reopened from a file."""
+    rng = np.random.default_rng(3)
+    cases = [oracle.gen_sphere(128, 7), oracle.gen_sphere(32, 3), rng.integers(0, 256, (32, 8, 16), dtype=np.uint8)]
+    for vol in cases:
+        z, y, x = vol.shape
+        ref = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=2).build()
+        bs = vr.BrickSet(1, (x, y, z), 1, 2).build(vol.copy())
+        D, M = ref.origTreeDepth, ref.maxTreeDepth
+        prev = None
+        for cut in sorted({0, 1, 5, D - 7, D - 6, D - 5, D - 1, D, D + 1, D + 3, M - 1, M}):
+            if cut < 0:
+                continue
+            got = bs.decode(cut_depth=cut).cpu().numpy().reshape(z, y, x)
+            assert np.array_equal(got, ref.levelCutProgressive(cut)), "cut %d" % cut
+        assert np.array_equal(bs.decode(cut_depth=M).cpu().numpy().reshape(z, y, x), ref.levelCut())
+        # foreign stream (file written by save(), reopened): same answers from the bytes alone
+        p = str(tmp_path / "t.bin")
+        bs.save(p)
+        fs = vr.BrickSet.open(p)
+        for cut in (0, 3, D - 6, D - 2, M):
+            if cut < 0:
+                continue
+            got = fs.decode(cut_depth=cut).cpu().numpy().reshape(z, y, x)
+            assert np.array_equal(got, ref.levelCutProgressive(cut)), "foreign cut %d" % cut

@@ -164,8 +164,8 @@ class VolumeKdtree:
     """volume_renderer/VolumeKdtree_recover.h:51-175 -- same method names and argument meaning.
 
     Differences forced by the defects listed in SURVEY.md Appendix C: the input is
-    not destroyed by build() (C-7: the error helpers need it), levelCut() is only
-    accepted at cutDepth == maxTreeDepth (C-4)."""
+    not destroyed by build() (C-7: the error helpers need it); levelCut() below
+    maxTreeDepth is a defined progressive cut rather than the reference's broken walk (C-4)."""
     _variant = _lib.VARIANT_RECOVER
 
     def __init__(self, inData=None, x=0, y=0, z=0):

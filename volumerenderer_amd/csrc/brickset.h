@@ -39,6 +39,8 @@ struct BrickSet {
     int64_t nEmitBlk = 0;
     uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)
     uint8_t *idxVal = nullptr;  // B * nIdx  decoded scalar of that root (or of the pruned ancestor)
+    uint8_t *idxValCut = nullptr; // B * nIdx  progressive cut above the index level: ancestor scalars
+    std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
 
     std::vector<Ctrl> hostCtrl; // copied back lazily
@@ -54,7 +56,9 @@ struct BrickSet {
 // kd_encode.hip
 int encode_launch(BrickSet *bs, const uint8_t *voxDev, hipStream_t st);
 // kd_decode.hip
-int decode_launch(BrickSet *bs, uint8_t *outDev, hipStream_t st);
+int decode_launch(BrickSet *bs, uint8_t *outDev, int cutDepth, hipStream_t st);
+int cut_values_from_stream(BrickSet *bs, const uint8_t *treeHost, int64_t numActive, const uint8_t *dmapHost, int cut,
+                           std::vector<uint8_t> &vals);
 int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *treeHost, int64_t numActive,
                             const uint8_t *dmapHost, std::vector<uint32_t> &offs, std::vector<uint8_t> &vals);
 void make_geom(Geom &g, const int64_t dims[3]);

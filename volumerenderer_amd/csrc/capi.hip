@@ -161,7 +161,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_stream2(b.rng);
     for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
     hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine);
-    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.lut);
+    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.lut);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;
     return VR_OK;
@@ -198,6 +198,7 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     if (rc == VR_OK) {
         hipError_t e = hipMalloc(&b.idxOff, (size_t)b.B * b.nIdx * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&b.idxVal, (size_t)b.B * b.nIdx);
+        if (e == hipSuccess) e = hipMalloc(&b.idxValCut, (size_t)b.B * b.nIdx);
         if (e == hipSuccess) e = hipMalloc(&b.lut, ((size_t)1 << b.K) * sizeof(uint32_t));
         if (e == hipSuccess) {
             std::vector<uint32_t> lut;
@@ -360,8 +361,22 @@ vr_status vr_brickset_decode(vr_brickset *h, int32_t cut_depth, uint8_t *out, vo
     if (!h || !out) return VR_ERR_INVALID;
     BrickSet &b = h->s;
     if (!b.built) return VR_ERR_STATE;
-    if (cut_depth >= 0 && cut_depth != b.maxDepth) return VR_ERR_UNSUPPORTED; // SURVEY C-4
-    if (decode_launch(&b, out, (hipStream_t)stream) != 0) return VR_ERR_NO_DEVICE;
+    if (cut_depth > b.maxDepth) return VR_ERR_INVALID;
+    const int cut = cut_depth < 0 ? b.maxDepth : cut_depth;
+    if (cut < b.Ds && b.foreign) {
+        // ancestor scalars at the cut depth, from the stream bytes kept at set_tree/open time
+        vr_status rc = sync_ctrl(b);
+        if (rc != VR_OK) return rc;
+        for (int br = 0; br < b.B; ++br) {
+            std::vector<uint8_t> vals((size_t)b.nIdx, 0);
+            if (br < (int)b.hostTree.size() && !b.hostTree[br].empty() &&
+                cut_values_from_stream(&b, b.hostTree[br].data(), (int64_t)b.hostCtrl[br].numActive,
+                                       b.hostCtrl[br].distanceMap, cut, vals) != 0)
+                return VR_ERR_FORMAT;
+            HIPCHK(hipMemcpy(b.idxValCut + (size_t)br * b.nIdx, vals.data(), vals.size(), hipMemcpyHostToDevice));
+        }
+    }
+    if (decode_launch(&b, out, cut, (hipStream_t)stream) != 0) return VR_ERR_NO_DEVICE;
     b.decodeTimingPending = true;
     b.lastStream = stream;
     return VR_OK;
@@ -400,6 +415,8 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     b.built = true;
     b.hostCtrlValid = true;
     b.foreign = true;
+    if ((int)b.hostTree.size() != b.B) b.hostTree.assign((size_t)b.B, std::vector<uint8_t>());
+    b.hostTree[brick].assign(tree, tree + need);
     return VR_OK;
 }
 

@@ -65,6 +65,8 @@ struct DecodeArgs {
     uint8_t *out;
     Geom g;
     int D, K, Ds;
+    int cut;                    // progressive cut depth (maxTreeDepth = the reference's levelCut)
+    const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
 };
 
 // v1: one lane per subtree, direct byte stores.
@@ -75,8 +77,10 @@ k_decode_lane(DecodeArgs a)
     const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= a.nIdx) return;
     const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
-    const int val0 = a.idxVal[(int64_t)brick * a.nIdx + s];
-    const uint8_t *dmap = a.ctrls[brick].distanceMap;
+    const int val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
+    const uint8_t *dmapG = a.ctrls[brick].distanceMap;
+    uint8_t dmap[VR_MAX_DEPTH + 8];
+    for (int q = 0; q <= a.D + VR_CHAIN_LEVELS; ++q) dmap[q] = q > a.cut ? 0 : dmapG[q];   // no refinement below the cut
     int ox, oy, oz;
     rank_to_xyz(a.g, (uint32_t)(s << a.K), ox, oy, oz);
     uint8_t *O = a.out + (int64_t)brick * a.g.voxels + ox + (int64_t)a.g.X * (oy + (int64_t)a.g.Y * oz);
@@ -148,6 +152,8 @@ struct TileArgs {
     int D, Ds;
     int jx, jy, jz;          // position of each axis among the three deepest split levels (0 = deepest)
     int tilesX, tilesY, tilesZ;
+    int cut;                    // progressive cut depth (maxTreeDepth = the reference's levelCut)
+    const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
 };
 
 #define DEC_WAVES 4
@@ -179,8 +185,10 @@ k_decode_tile(TileArgs a)
     if (threadIdx.x < 16) {
         const uint8_t *dmap = a.ctrls[brick].distanceMap;
         const int t = threadIdx.x;
-        // [0] = 0: the subtree root keeps the value stored in the index
-        dmS[t] = t == 0 ? 0 : (t < 8 ? dmap[a.Ds + (t < 7 ? t : 0)] : dmap[a.D + (t - 8)]);
+        // [0] = 0: the subtree root keeps the value stored in the index; levels below a progressive cut
+        // refine nothing (distance 0), so every voxel gets the scalar of its ancestor at the cut depth
+        const int depth = t < 8 ? a.Ds + (t < 7 ? t : 0) : a.D + (t - 8);
+        dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];
     }
     __syncthreads();
     if (threadIdx.x < 128) {
@@ -219,7 +227,7 @@ k_decode_tile(TileArgs a)
     uint32_t s = 0;
     for (int d = 0; d < a.Ds; ++d) s = (s << 1) | ((uint32_t)(sc[a.g.axis[d]] >> (a.g.bit[d] - 2)) & 1u);
     const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
-    const int val0 = a.idxVal[(int64_t)brick * a.nIdx + s];
+    const int val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
 
     {
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
@@ -346,14 +354,38 @@ static bool tile_geometry(const BrickSet *bs, TileArgs &a)
     return true;
 }
 
-int decode_launch(BrickSet *bs, uint8_t *out, hipStream_t st)
+// scalar of every depth-Ds subtree's ancestor at depth `cut` (< Ds), from the encoder's BFS codes
+__global__ void __launch_bounds__(256)
+k_cut_values(const uint8_t *__restrict__ codes, int64_t heapStride, const Ctrl *ctrls, int Ds, int cut, int64_t nIdx,
+             uint8_t *__restrict__ out)
+{
+    const int brick = blockIdx.y;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nIdx) return;
+    const uint8_t *Cb = codes + (int64_t)brick * heapStride;
+    const uint8_t *dmap = ctrls[brick].distanceMap;
+    int val = dmap[0];
+    for (int j = 1; j <= cut; ++j) val = apply_code(val, Cb[((int64_t)1 << j) + (s >> (Ds - j))], dmap[j]);
+    out[(int64_t)brick * nIdx + s] = (uint8_t)val;
+}
+
+int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
 {
     hipEventRecord(bs->ev[5], st);
+    const uint8_t *cutVals = nullptr;
+    if (cut < bs->Ds) {
+        if (!bs->idxValCut) return -2;
+        if (!bs->foreign)
+            hipLaunchKernelGGL(k_cut_values, dim3((unsigned)((bs->nIdx + 255) / 256), bs->B), dim3(256), 0, st,
+                               bs->mid.codes, bs->heapStride, bs->mid.ctrl, bs->Ds, cut, bs->nIdx, bs->idxValCut);
+        cutVals = bs->idxValCut;   // foreign streams: filled by the host from the bytes (capi)
+    }
     TileArgs t;
     if (!getenv("VRHIP_DECODE_V1") && tile_geometry(bs, t)) {
         t.tree = bs->mid.tree; t.treeCap = bs->treeCap;
         t.idxOff = bs->idxOff; t.idxVal = bs->idxVal; t.nIdx = bs->nIdx;
         t.ctrls = bs->mid.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
+        t.cut = cut; t.idxValCut = cutVals;
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
         hipLaunchKernelGGL(k_decode_tile, dim3((unsigned)((ntiles + DEC_WAVES - 1) / DEC_WAVES), bs->B),
                            dim3(64 * DEC_WAVES), 0, st, t);
@@ -363,10 +395,52 @@ int decode_launch(BrickSet *bs, uint8_t *out, hipStream_t st)
         a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
         a.ctrls = bs->mid.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
         a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
+        a.cut = cut; a.idxValCut = cutVals;
         hipLaunchKernelGGL(k_decode_lane, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
     }
     hipEventRecord(bs->ev[6], st);
     return launch_status("decode");
+}
+
+// Foreign stream, progressive cut above the index level: scalar of every depth-Ds subtree's ancestor at
+// depth `cut` (< Ds), from the bytes alone.
+int cut_values_from_stream(BrickSet *bs, const uint8_t *tree, int64_t numActive, const uint8_t *dmap, int cut,
+                           std::vector<uint8_t> &vals)
+{
+    const int D = bs->D, Ds = bs->Ds;
+    vals.assign((size_t)bs->nIdx, 0);
+    auto get = [&](int64_t p) { return (tree[p >> 2] >> ((p & 3) * 2)) & 3; };
+    int v[VR_MAX_DEPTH];
+    int64_t pos = 0;
+    int j = 0;
+    uint32_t path = 0;
+    while (true) {
+        if (pos >= numActive) return -1;
+        int tok = get(pos++);
+        int val = j == 0 ? dmap[0] : (j <= cut ? apply_code(v[j - 1], tok, dmap[j]) : v[j - 1]);
+        v[j] = val;
+        if (j == Ds) vals[path] = (uint8_t)val;
+        bool terminal = false;
+        if (tok == 3) {
+            if (j < Ds) {
+                uint32_t lo = path << (Ds - j), hi = (path + 1) << (Ds - j);
+                for (uint32_t q = lo; q < hi; ++q) vals[q] = (uint8_t)val;
+            }
+            terminal = true;
+        } else if (j == D) {
+            for (int c = 1; c <= VR_CHAIN_LEVELS; ++c) {
+                if (pos >= numActive) return -2;
+                if (get(pos++) == 3) break;
+            }
+            terminal = true;
+        }
+        if (terminal) {
+            while (j > 0 && (path & 1u)) { path >>= 1; --j; }
+            if (j == 0) break;
+            path |= 1u;
+        } else { ++j; path <<= 1; }
+    }
+    return pos == numActive ? 0 : -3;
 }
 
 // Serial pass over a foreign stream (host): the side-car index from the bytes alone.
