@@ -29,9 +29,14 @@ def build(force=False):
     stamp = _LIB_PATH + ".srchash"
     fresh = os.path.exists(_LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == _source_hash()
     if force or not fresh:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
-        with open(stamp, "w") as f:
-            f.write(_source_hash())
+        import fcntl
+        with open(_LIB_PATH + ".lock", "w") as lk:      # ranks of one node: one builds, the others wait
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            fresh = os.path.exists(_LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == _source_hash()
+            if force or not fresh:
+                subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+                with open(stamp, "w") as f:
+                    f.write(_source_hash())
     return _LIB_PATH
 
 

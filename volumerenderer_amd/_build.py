@@ -35,13 +35,20 @@ def _stale():
 def build(force=False, verbose=False):
     if not (force or _stale()):
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    with open(STAMP, "w") as f:
-        f.write(_source_hash())
+    import fcntl
+    # several ranks of one node may get here together: one builds, the others wait and re-check
+    with open(LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if force or _stale():
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+            os.replace(tmp, LIB)
+            with open(STAMP, "w") as f:
+                f.write(_source_hash())
     return LIB
 
 
