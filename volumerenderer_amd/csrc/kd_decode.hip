@@ -174,7 +174,8 @@ k_decode_tile(TileArgs a)
     __shared__ uint32_t strS[DEC_WAVES][DEC_SW * 64];   // [word][lane]
     __shared__ uint8_t stkS[DEC_WAVES][8 * 64];         // [level][lane]
     __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
-    __shared__ uint32_t lutS[128];   // token-step action table (built below from dmS)
+    __shared__ uint32_t lutS[32];    // tree-token action table (built below from dmS)
+    __shared__ uint32_t lutC1[256], lutC2[64];   // grown-branch tables: branch tokens 1-4 and 5-7
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * DEC_WAVES + wave;
@@ -191,32 +192,41 @@ k_decode_tile(TileArgs a)
         dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];
     }
     __syncthreads();
-    if (threadIdx.x < 128) {
-        // action table: rows 0..6 tree level j, row 8 = branch exhausted, rows 9..15 = branch step 1..7
-        const int key = threadIdx.x, row = key >> 3, tok = (key >> 1) & 3, nxt3 = key & 1;
-        int delta = 0, usedx = 2, term = 0, desc = 0, nchain = 0, count = 1;
-        if (row < 8) {
-            const int j = row;
-            const bool is3 = tok == 3, lf = !is3 && j == 6;
-            desc = (!is3 && j < 6) ? 1 : 0;
-            term = (is3 || (lf && nxt3)) ? 1 : 0;
-            usedx = (lf && nxt3) ? 4 : 2;
-            nchain = (lf && !nxt3) ? 1 : 0;
-            count = is3 ? (64 >> (j > 6 ? 6 : j)) : 1;
-            const int dist = dmS[j > 6 ? 0 : j];
-            delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
-        } else {
-            const int cidx = row - 8;                 // 0: exhausted
-            const bool exhausted = cidx == 0, is3 = !exhausted && tok == 3, last = !exhausted && cidx >= VR_CHAIN_LEVELS;
-            term = (exhausted || is3 || last || nxt3) ? 1 : 0;
-            usedx = exhausted ? 0 : 2 + ((!is3 && !last && nxt3) ? 2 : 0);
-            nchain = term ? 0 : cidx + 1;
-            const int dist = dmS[8 + cidx];
-            delta = (exhausted || is3) ? 0 : (tok == 1 ? dist : (tok == 2 ? -dist : 0));
-        }
+    if (threadIdx.x < 32) {
+        // tree-token action table: [level j][code]
+        const int key = threadIdx.x, j = key >> 2, tok = key & 3;
+        const bool is3 = tok == 3, lf = !is3 && j == 6;
+        const int desc = (!is3 && j < 6) ? 1 : 0;
+        const int term = (is3 || lf) ? 1 : 0;                 // a leaf's branch is consumed in the same step
+        const int count = is3 ? (64 >> (j > 6 ? 6 : j)) : 1;
+        const int dist = dmS[j > 6 ? 0 : j];
+        const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
         const int single = (term && count == 1) ? 1 : 0, fillc = (term && count > 1) ? count : 0;
-        lutS[key] = (uint32_t)(delta + 256) | ((uint32_t)(usedx >> 1) << 10) | ((uint32_t)term << 12) | ((uint32_t)desc << 13) |
-                    ((uint32_t)nchain << 14) | ((uint32_t)fillc << 20) | ((uint32_t)single << 27);
+        lutS[key] = (uint32_t)(delta + 256) | ((uint32_t)term << 12) | ((uint32_t)desc << 13) | ((uint32_t)(lf ? 1 : 0) << 14) |
+                    ((uint32_t)fillc << 20) | ((uint32_t)single << 27);
+    }
+    {
+        // grown-branch tables: compose v -> min(max(v + A, LO), HI) over steps first..first+n-1
+        // (distances dmS[8 + step]); stop at a terminator (code 3).
+        const int idx = threadIdx.x;                      // 256 threads: table 1 has 256 entries, table 2 uses 64
+        for (int tb = 0; tb < 2; ++tb) {
+            const int first = tb == 0 ? 1 : 5, n = tb == 0 ? 4 : 3;
+            if (tb == 1 && idx >= 64) break;
+            int A = 0, LO = 0, HI = 255, len = 0, term = 0;
+            for (int q = 0; q < n; ++q) {
+                const int tok = (idx >> (2 * q)) & 3;
+                ++len;
+                if (tok == 3) { term = 1; break; }
+                const int dist = dmS[8 + first + q];
+                const int dl = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+                A += dl;
+                LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
+                HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
+            }
+            const uint32_t ent = (uint32_t)(A + 256) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) |
+                                 ((uint32_t)term << 29);
+            if (tb == 0) lutC1[idx] = ent; else lutC2[idx] = ent;
+        }
     }
     __syncthreads();
     if (!tileValid) return;
@@ -236,7 +246,6 @@ k_decode_tile(TileArgs a)
         uint32_t wbase = dead ? 0u : (off >> 4);
         uint32_t bitpos = dead ? 0u : (off & 15u) * 2u;     // relative to the staged window
         uint32_t p = 1;                 // path with a leading sentinel bit: depth = bitlen(p) - 1
-        int chain = 0;                  // 0: tree token expected, 1..7: next grown-branch step
         int v = val0;
         int fill = dead ? 64 : 0;       // voxels of a pruned node still to write
         int leaf = 0;                   // next leaf (Morton rank) to emit
@@ -252,10 +261,12 @@ k_decode_tile(TileArgs a)
             for (int k = 0; k < DEC_SW; ++k) str[k * 64 + lane] = W[wbase + k];
             __builtin_amdgcn_s_waitcnt(0xC07F);
             // ---- walk while somebody can still look ahead.  The body is branch-free per lane:
-            // everything a token step decides (signed value delta, bits consumed, terminal?,
-            // descend?, next branch step, fill size) comes packed from a 128-entry LDS table
-            // keyed by (mode, level or branch step, code, "terminator follows"), so the per-lane
-            // booleans never reach the scalar unit as exec-mask algebra.
+            // what a tree token decides (signed value delta, terminal?, descend?, fill size) comes
+            // packed from an LDS table keyed by (level, code); a voxel leaf's whole grown branch
+            // (up to 7 more tokens incl. terminator) is folded into the same step through two more
+            // tables that hold, for 4 + 3 branch tokens, the composed clamp-add v -> min(max(v+A,LO),HI),
+            // the tokens consumed and whether a terminator ended it.  So a lane spends one iteration
+            // per tree node and none on branch tokens, and its booleans never become exec-mask algebra.
             while (true) {
                 const bool act = !done && (bitpos >> 5) < DEC_SW - 2;
                 if (__ballot(act) == 0ull) break;
@@ -273,31 +284,30 @@ k_decode_tile(TileArgs a)
                 const uint32_t k = bitpos >> 5;
                 const uint32_t w0 = str[k * 64 + lane], w1 = str[(k + 1) * 64 + lane];
                 const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);   // 16 tokens ahead
-                const uint32_t tree = chain == 0 ? 1u : 0u;
                 const uint32_t j = (31u - (uint32_t)__clz((int)p)) & 7u;
-                // grown branch: skip the run of "keep" codes (sentinel bit stops the count at the branch end)
-                const uint32_t rem = 8u - (uint32_t)chain;
-                const uint32_t zr = (uint32_t)(__ffs((int)(x | (1u << (2u * rem)))) - 1) >> 1;
-                const uint32_t z = tree ? 0u : zr;
-                const uint32_t exhausted = (!tree && zr == rem) ? 1u : 0u;     // only keeps up to depth D+7
-                const uint32_t xs = x >> (2u * z);
-                const uint32_t tok = xs & 3u;
-                const uint32_t n3 = ((xs >> 2) & 3u) == 3u ? 1u : 0u;           // a terminator follows
-                const uint32_t row = tree ? j : (exhausted ? 8u : 8u + (uint32_t)chain + z);
-                const uint32_t e = lutS[row * 8u + (exhausted ? 0u : tok * 2u + n3)];
+                const uint32_t e = lutS[j * 4u + (x & 3u)];
+                const uint32_t e1 = lutC1[(x >> 2) & 255u], e2 = lutC2[(x >> 10) & 63u];
                 const int sv = stk[((j + 7u) & 7u) * 64 + lane];
-                int nv = (tree ? sv : v) + (int)(e & 1023u) - 256;
+                int nv = sv + (int)(e & 1023u) - 256;
                 nv = nv < 0 ? 0 : (nv > 255 ? 255 : nv);                        // decoder step R.cpp:783-787
+                // grown branch of a voxel leaf: first 4 tokens, then (unless terminated) 3 more
+                int b1 = nv + (int)(e1 & 1023u) - 256;
+                { const int lo = (int)((e1 >> 10) & 255u), hi = (int)((e1 >> 18) & 255u); b1 = b1 < lo ? lo : (b1 > hi ? hi : b1); }
+                int b2 = b1 + (int)(e2 & 1023u) - 256;
+                { const int lo = (int)((e2 >> 10) & 255u), hi = (int)((e2 >> 18) & 255u); b2 = b2 < lo ? lo : (b2 > hi ? hi : b2); }
+                const uint32_t lf = (e >> 14) & 1u;                              // voxel leaf with a branch behind it
+                const uint32_t more = lf & ~(e1 >> 29) & 1u;                     // first four were no terminator
+                const uint32_t clen = ((e1 >> 26) & 7u) + (more ? ((e2 >> 26) & 7u) : 0u);
+                const int vo = lf ? (more ? b2 : b1) : nv;
                 const uint32_t desc = (e >> 13) & tk;
                 const uint32_t t = (e >> 12) & tk;
                 const uint32_t single = (e >> 27) & tk;
                 const uint32_t fillc = (e >> 20) & 127u;
-                v = tk ? nv : v;
+                v = tk ? vo : v;
                 stk[(desc ? j : 6u) * 64 + lane] = (uint8_t)nv;
                 p <<= desc;
-                chain = tk ? (int)((e >> 14) & 7u) : chain;
-                bitpos += tk ? 2u * z + ((e >> 10) & 3u) * 2u : 0u;
-                tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)nv;
+                bitpos += tk ? 2u + (lf ? 2u * clen : 0u) : 0u;
+                tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)vo;
                 leaf += (int)single;
                 fill = (t && fillc) ? (int)fillc : fill;
                 uint32_t np = p + 1u;
