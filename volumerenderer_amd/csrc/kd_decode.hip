@@ -158,7 +158,7 @@ struct TileArgs {
 
 #define DEC_WAVES 4
 #define DEC_DUMMY_ROW 64
-#define DEC_SW 16            // staged words per lane (usable lookahead: DEC_SW-2 words per stage)
+#define DEC_SW 32            // staged words per lane (usable lookahead: DEC_SW-2 words per stage)
 
 __device__ __forceinline__ int clamp_add(int pv, int tok, int dist)
 {   // decoder step R.cpp:783-787 / 814-818, branch-free
