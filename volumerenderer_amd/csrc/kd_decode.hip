@@ -160,6 +160,13 @@ struct TileArgs {
 #define DEC_DUMMY_ROW 64
 #define DEC_SW 32            // staged words per lane (usable lookahead: DEC_SW-2 words per stage)
 
+__device__ __forceinline__ int med3i(int x, int lo, int hi)
+{   // min(max(x, lo), hi) for lo <= hi in one instruction
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ int clamp_add(int pv, int tok, int dist)
 {   // decoder step R.cpp:783-787 / 814-818, branch-free
     const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
@@ -202,8 +209,10 @@ k_decode_tile(TileArgs a)
         const int dist = dmS[j > 6 ? 0 : j];
         const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
         const int single = (term && count == 1) ? 1 : 0, fillc = (term && count > 1) ? count : 0;
-        lutS[key] = (uint32_t)(delta + 256) | ((uint32_t)term << 12) | ((uint32_t)desc << 13) | ((uint32_t)(lf ? 1 : 0) << 14) |
-                    ((uint32_t)fillc << 20) | ((uint32_t)single << 27);
+        // row 7 (keys 28..31) is the no-op entry idle lanes read: delta 0, 0 bits consumed, no flags
+        lutS[key] = j == 7 ? 256u
+                           : ((uint32_t)(delta + 256) | (2u << 10) | ((uint32_t)term << 12) | ((uint32_t)desc << 13) |
+                              ((uint32_t)(lf ? 1 : 0) << 14) | ((uint32_t)fillc << 20) | ((uint32_t)single << 27));
     }
     {
         // grown-branch tables: compose v -> min(max(v + A, LO), HI) over steps first..first+n-1
@@ -280,36 +289,34 @@ k_decode_tile(TileArgs a)
                     leaf += n4; fill -= n4;
                     done = done || (filling && fill == 0 && p == 0x80000000u);
                 }
-                const uint32_t tk = (act && !filling) ? 1u : 0u;   // this lane consumes tokens now
+                const bool tk = act && !filling;                    // this lane consumes tokens now
                 const uint32_t k = bitpos >> 5;
                 const uint32_t w0 = str[k * 64 + lane], w1 = str[(k + 1) * 64 + lane];
                 const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);   // 16 tokens ahead
                 const uint32_t j = (31u - (uint32_t)__clz((int)p)) & 7u;
-                const uint32_t e = lutS[j * 4u + (x & 3u)];
+                // idle lanes read the all-zero row 7: nothing is consumed, written or changed
+                const uint32_t e = lutS[tk ? j * 4u + (x & 3u) : 28u];
                 const uint32_t e1 = lutC1[(x >> 2) & 255u], e2 = lutC2[(x >> 10) & 63u];
                 const int sv = stk[((j + 7u) & 7u) * 64 + lane];
-                int nv = sv + (int)(e & 1023u) - 256;
-                nv = nv < 0 ? 0 : (nv > 255 ? 255 : nv);                        // decoder step R.cpp:783-787
+                const int nv = med3i(sv + (int)(e & 1023u) - 256, 0, 255);      // decoder step R.cpp:783-787
                 // grown branch of a voxel leaf: first 4 tokens, then (unless terminated) 3 more
-                int b1 = nv + (int)(e1 & 1023u) - 256;
-                { const int lo = (int)((e1 >> 10) & 255u), hi = (int)((e1 >> 18) & 255u); b1 = b1 < lo ? lo : (b1 > hi ? hi : b1); }
-                int b2 = b1 + (int)(e2 & 1023u) - 256;
-                { const int lo = (int)((e2 >> 10) & 255u), hi = (int)((e2 >> 18) & 255u); b2 = b2 < lo ? lo : (b2 > hi ? hi : b2); }
+                const int b1 = med3i(nv + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
+                const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
                 const uint32_t lf = (e >> 14) & 1u;                              // voxel leaf with a branch behind it
-                const uint32_t more = lf & ~(e1 >> 29) & 1u;                     // first four were no terminator
+                const uint32_t more = lf & ~(e1 >> 29);                          // first four were no terminator
                 const uint32_t clen = ((e1 >> 26) & 7u) + (more ? ((e2 >> 26) & 7u) : 0u);
                 const int vo = lf ? (more ? b2 : b1) : nv;
-                const uint32_t desc = (e >> 13) & tk;
-                const uint32_t t = (e >> 12) & tk;
-                const uint32_t single = (e >> 27) & tk;
+                const uint32_t desc = (e >> 13) & 1u;
+                const bool t = ((e >> 12) & 1u) != 0u;
+                const uint32_t single = (e >> 27) & 1u;
                 const uint32_t fillc = (e >> 20) & 127u;
                 v = tk ? vo : v;
                 stk[(desc ? j : 6u) * 64 + lane] = (uint8_t)nv;
                 p <<= desc;
-                bitpos += tk ? 2u + (lf ? 2u * clen : 0u) : 0u;
+                bitpos += ((e >> 10) & 3u) + (lf ? 2u * clen : 0u);
                 tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)vo;
                 leaf += (int)single;
-                fill = (t && fillc) ? (int)fillc : fill;
+                fill = fillc ? (int)fillc : fill;
                 uint32_t np = p + 1u;
                 np >>= (__ffs((int)np) - 1);
                 const bool parked = t && np == 1u;              // no further tokens are mine
