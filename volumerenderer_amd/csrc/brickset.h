@@ -8,7 +8,7 @@ namespace vr {
 
 struct Stream2 {              // one 2-bit stream (mid, or MidRangeTree's half-range stream)
     uint8_t *temp = nullptr;  // B * heapStride   truth heap (midrange / half range), 1-based
-    uint8_t *codes = nullptr; // B * heapStride   2-bit codes, one per byte, 1-based heap (BFS)
+    uint8_t *codes = nullptr; // B * codeStride   2-bit codes, four per byte (TwoBitArray packing), 1-based heap (BFS)
     uint8_t *recon[3] = {nullptr, nullptr, nullptr}; // B * leafStride each: parents + two level buffers
     Ctrl *ctrl = nullptr;     // B
     uint8_t *tree = nullptr;  // B * treeCap      preorder stream, TwoBitArray packing
@@ -23,6 +23,7 @@ struct BrickSet {
     int32_t Ds = 0;           // D - K
     int64_t heapStride = 0;   // 2^(D+1)
     int64_t leafStride = 0;   // 2^D
+    int64_t codeStride = 0;   // bytes of packed BFS codes per brick: heapStride / 4, 4-byte aligned
     int64_t treeCap = 0;      // bytes per brick reserved for the preorder stream
     int64_t nIdx = 0;         // 2^Ds index entries per brick
 

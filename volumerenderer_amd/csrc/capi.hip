@@ -114,7 +114,7 @@ static vr_status alloc_stream2(BrickSet &b, Stream2 &s, bool encoder)
     HIPCHK(hipMalloc(&s.tree, B * (size_t)b.treeCap));
     if (encoder) {
         HIPCHK(hipMalloc(&s.temp, B * (size_t)b.heapStride));
-        HIPCHK(hipMalloc(&s.codes, B * (size_t)b.heapStride));
+        HIPCHK(hipMalloc(&s.codes, B * (size_t)b.codeStride));
         for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&s.recon[i], B * (size_t)b.leafStride));
     }
     return VR_OK;
@@ -125,13 +125,13 @@ static vr_status ensure_encoder_buffers(BrickSet &b)
     if (b.mid.temp) return VR_OK;
     const size_t B = (size_t)b.B;
     HIPCHK(hipMalloc(&b.mid.temp, B * (size_t)b.heapStride));
-    HIPCHK(hipMalloc(&b.mid.codes, B * (size_t)b.heapStride));
+    HIPCHK(hipMalloc(&b.mid.codes, B * (size_t)b.codeStride));
     for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.mid.recon[i], B * (size_t)b.leafStride));
     if (b.variant == VR_VARIANT_MIDRANGE) {
         HIPCHK(hipMalloc(&b.rng.ctrl, B * sizeof(Ctrl)));
         HIPCHK(hipMalloc(&b.rng.tree, B * (size_t)b.treeCap));
         HIPCHK(hipMalloc(&b.rng.temp, B * (size_t)b.heapStride));
-        HIPCHK(hipMalloc(&b.rng.codes, B * (size_t)b.heapStride));
+        HIPCHK(hipMalloc(&b.rng.codes, B * (size_t)b.codeStride));
         for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.rng.recon[i], B * (size_t)b.leafStride));
     }
     const int64_t mm = (int64_t)1 << (b.D > 10 ? b.D - 10 : 0);
@@ -191,6 +191,7 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     b.Ds = b.D - b.K;
     b.heapStride = (int64_t)1 << (b.D + 1);
     b.leafStride = (int64_t)1 << b.D;
+    b.codeStride = ((b.heapStride + 15) / 16) * 4;
     const int64_t numMax = b.heapStride - 1 + VR_CHAIN_LEVELS * b.leafStride; // numMaxNodes R.cpp:35
     b.treeCap = ((numMax + 15) / 16 + 2) * 4 + 256;   // slack: the decoder stages whole words past a run's end
     b.nIdx = (int64_t)1 << b.Ds;

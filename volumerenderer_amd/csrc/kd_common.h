@@ -90,6 +90,19 @@ __host__ __device__ inline int apply_code(int v, int code, int dist)
     return v;
 }
 
+// The breadth-first 2-bit codes are packed four per byte in heap order (TwoBitArray packing:
+// element i in byte i/4, bits 2*(i&3)).
+__host__ __device__ inline int cget(const uint8_t *C, int64_t i) { return (C[i >> 2] >> ((int)(i & 3) * 2)) & 3; }
+#ifdef __HIPCC__
+// Prune only ever turns a 0 into a 3, so an atomic OR of the two bits is race-free whoever
+// shares the byte (the per-brick code array is 4-byte aligned).
+__device__ inline void cset3(uint8_t *C, int64_t i)
+{
+    const int64_t b = i >> 2;
+    atomicOr((uint32_t *)(C + (b & ~(int64_t)3)), 3u << ((int)(b & 3) * 8 + (int)(i & 3) * 2));
+}
+#endif
+
 // launch check used by every host launcher: 0 on success; prints the HIP error when
 // VRHIP_DEBUG is set in the environment.
 int launch_status(const char *what);

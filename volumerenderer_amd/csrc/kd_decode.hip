@@ -373,16 +373,16 @@ static bool tile_geometry(const BrickSet *bs, TileArgs &a)
 
 // scalar of every depth-Ds subtree's ancestor at depth `cut` (< Ds), from the encoder's BFS codes
 __global__ void __launch_bounds__(256)
-k_cut_values(const uint8_t *__restrict__ codes, int64_t heapStride, const Ctrl *ctrls, int Ds, int cut, int64_t nIdx,
+k_cut_values(const uint8_t *__restrict__ codes, int64_t codeStride, const Ctrl *ctrls, int Ds, int cut, int64_t nIdx,
              uint8_t *__restrict__ out)
 {
     const int brick = blockIdx.y;
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= nIdx) return;
-    const uint8_t *Cb = codes + (int64_t)brick * heapStride;
+    const uint8_t *Cb = codes + (int64_t)brick * codeStride;
     const uint8_t *dmap = ctrls[brick].distanceMap;
     int val = dmap[0];
-    for (int j = 1; j <= cut; ++j) val = apply_code(val, Cb[((int64_t)1 << j) + (s >> (Ds - j))], dmap[j]);
+    for (int j = 1; j <= cut; ++j) val = apply_code(val, cget(Cb, ((int64_t)1 << j) + (s >> (Ds - j))), dmap[j]);
     out[(int64_t)brick * nIdx + s] = (uint8_t)val;
 }
 
@@ -394,7 +394,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
         if (!bs->idxValCut) return -2;
         if (!bs->foreign)
             hipLaunchKernelGGL(k_cut_values, dim3((unsigned)((bs->nIdx + 255) / 256), bs->B), dim3(256), 0, st,
-                               bs->mid.codes, bs->heapStride, bs->mid.ctrl, bs->Ds, cut, bs->nIdx, bs->idxValCut);
+                               bs->mid.codes, bs->codeStride, bs->mid.ctrl, bs->Ds, cut, bs->nIdx, bs->idxValCut);
         cutVals = bs->idxValCut;   // foreign streams: filled by the host from the bytes (capi)
     }
     TileArgs t;

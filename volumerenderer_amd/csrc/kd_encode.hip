@@ -427,7 +427,7 @@ __device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigne
 // reference's serial double sum) and at current-1 / current+1 (exact integer atomics).
 __global__ void __launch_bounds__(256)
 k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
-       ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+       int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
 {
     __shared__ unsigned long long sh[4];
     const int brick = blockIdx.y;
@@ -435,7 +435,7 @@ k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict
     if (!c.fillThisEpoch) return;
     const uint32_t n = 1u << d;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
-    uint8_t *Cd = codes + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    uint8_t *Cb = codes + (int64_t)brick * codeStride;
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
     uint8_t *R = rb.b[phys_buf(c, c.cur)] + (int64_t)brick * leafStride;
     const int dist = (int)(uint8_t)c.currentDistance;
@@ -443,6 +443,7 @@ k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict
     const int distP = (int)(uint8_t)fmin(255.0, c.currentDistance + 1.0);
     unsigned long long e0 = 0, em = 0, ep = 0;
     const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    uint32_t pk = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         uint32_t i = i0 + k;
@@ -450,13 +451,18 @@ k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict
             int t = T[i];
             int p = d > 0 ? P[i >> 1] : 0;
             Enc e = encode_node(t, p, dist);
-            Cd[i] = (uint8_t)e.code;
+            pk |= (uint32_t)e.code << (2 * k);
             R[i] = (uint8_t)e.recon;
             e0 += (unsigned)(e.err * e.err);
             int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
             em += (unsigned)(a * a);
             ep += (unsigned)(b * b);
         }
+    }
+    if (i0 < n) {
+        if (d >= 2) Cb[(((int64_t)1 << d) + i0) >> 2] = (uint8_t)pk;     // four codes = one whole byte
+        else if (d == 0) Cb[0] = (uint8_t)((Cb[0] & ~0x0Cu) | (pk << 2));            // heap node 1 (only writer)
+        else Cb[0] = (uint8_t)((Cb[0] & 0x0Fu) | ((pk & 0xFu) << 4));                 // heap nodes 2, 3
     }
     e0 = block_sum_u64(e0, sh);
     em = block_sum_u64(em, sh);
@@ -479,14 +485,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 __global__ void __launch_bounds__(256)
 k_fill16(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
-         ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+         int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
 {
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
     Ctrl &c = ctrls[brick];
     if (!c.fillThisEpoch) return;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
-    uint8_t *Cd = codes + (int64_t)brick * heapStride + ((int64_t)1 << d);
+    uint8_t *Cd = codes + (int64_t)brick * codeStride + ((int64_t)1 << (d - 2));   // packed: 4 codes per byte
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
     uint8_t *R = rb.b[phys_buf(c, c.cur)] + (int64_t)brick * leafStride;
     const int dist = (int)(uint8_t)c.currentDistance;
@@ -496,20 +502,20 @@ k_fill16(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restri
     const uint4 tv = *(const uint4 *)(T + i0);
     const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
-    uint32_t cw[4] = {0, 0, 0, 0}, rw[4] = {0, 0, 0, 0};
+    uint32_t cpk = 0, rw[4] = {0, 0, 0, 0};
     uint32_t e0 = 0, em = 0, ep = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int t = (tw[k >> 2] >> ((k & 3) * 8)) & 255, p = (pw[k >> 3] >> (((k >> 1) & 3) * 8)) & 255;
         const Enc e = encode_node(t, p, dist);
-        cw[k >> 2] |= (uint32_t)e.code << ((k & 3) * 8);
+        cpk |= (uint32_t)e.code << (2 * k);
         rw[k >> 2] |= (uint32_t)e.recon << ((k & 3) * 8);
         e0 += (uint32_t)(e.err * e.err);
         const int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
         em += (uint32_t)(a * a);
         ep += (uint32_t)(b * b);
     }
-    *(uint4 *)(Cd + i0) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
     *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
     const unsigned long long s0 = wave_sum_u64(e0), sm = wave_sum_u64(em), sp = wave_sum_u64(ep);
     const int w = threadIdx.x >> 6;
@@ -678,7 +684,8 @@ __global__ void k_level_end(int d, Ctrl *ctrls)
 // ------------------------------------------------------------------ prune ----
 __global__ void __launch_bounds__(256)
 k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
-             uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride, int maxDepth,
+             uint8_t *__restrict__ codesRange, int64_t heapStride, int64_t codeStride, ReconBufs rb, int64_t leafStride,
+             int maxDepth,
              unsigned long long *__restrict__ blockL1, int64_t nEmitBlk)
 {
     __shared__ unsigned long long shl[4];
@@ -693,10 +700,13 @@ k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint
         int rec = rb.b[c.par][(int64_t)brick * leafStride + r];
         err = rec > t ? rec - t : t - rec;
         fe = err;
-        if (codes[hi] == 0 && err < tol) {   // R.cpp:618-626 (leaf: no children)
-            codes[hi] = 3;
-            if (codesRange) codesRange[hi] = 3;
-        } else if (codes[hi] != 3) {         // an unpruned leaf is always live: its error after branch growth
+        uint8_t *Cb = codes + (int64_t)brick * codeStride;
+        const int64_t ci = ((int64_t)1 << D) + r;
+        const int code = cget(Cb, ci);
+        if (code == 0 && err < tol) {        // R.cpp:618-626 (leaf: no children)
+            cset3(Cb, ci);
+            if (codesRange) cset3(codesRange + (int64_t)brick * codeStride, ci);
+        } else if (code != 3) {              // an unpruned leaf is always live: its error after branch growth
             int depth = D;
             while (depth < maxDepth) {
                 const int e2 = rec > t ? rec - t : t - rec;
@@ -724,17 +734,17 @@ k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint
 }
 
 __global__ void __launch_bounds__(256)
-k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRange, int64_t heapStride)
+k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRange, int64_t codeStride)
 {
     const int brick = blockIdx.y;
     const uint32_t n = 1u << d;
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
-    uint8_t *Cb = codes + (int64_t)brick * heapStride;
+    uint8_t *Cb = codes + (int64_t)brick * codeStride;
     const int64_t me = ((int64_t)1 << d) + p, ch = ((int64_t)1 << (d + 1)) + 2 * (int64_t)p;
-    if (Cb[ch] == 3 && Cb[ch + 1] == 3 && Cb[me] == 0) {  // R.cpp:624
-        Cb[me] = 3;
-        if (codesRange) codesRange[(int64_t)brick * heapStride + me] = 3;
+    if (cget(Cb, ch) == 3 && cget(Cb, ch + 1) == 3 && cget(Cb, me) == 0) {  // R.cpp:624
+        cset3(Cb, me);
+        if (codesRange) cset3(codesRange + (int64_t)brick * codeStride, me);
     }
 }
 
@@ -745,8 +755,8 @@ k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRan
 // depends on its two children.
 __global__ void __launch_bounds__(256)
 k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
-          uint8_t *__restrict__ codesRange, int64_t heapStride, ReconBufs rb, int64_t leafStride, int maxDepth,
-          uint32_t *__restrict__ subTok, int64_t nEmitBlk, unsigned long long *__restrict__ blockL1)
+          uint8_t *__restrict__ codesRange, int64_t heapStride, int64_t codeStride, ReconBufs rb, int64_t leafStride,
+          int maxDepth, uint32_t *__restrict__ subTok, int64_t nEmitBlk, unsigned long long *__restrict__ blockL1)
 {
     __shared__ uint8_t fl[2][2048];
     __shared__ uint16_t cnt[2][2048];      // tokens a (live) subtree emits, carried upwards with the flags
@@ -754,19 +764,18 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     const int brick = blockIdx.y, t = threadIdx.x;
     Ctrl &c = ctrls[brick];
     const uint32_t base = blockIdx.x << 12;
-    uint8_t *Cb = codes + (int64_t)brick * heapStride;
-    uint8_t *CR = codesRange ? codesRange + (int64_t)brick * heapStride : nullptr;
+    uint8_t *Cb = codes + (int64_t)brick * codeStride;
+    uint8_t *CR = codesRange ? codesRange + (int64_t)brick * codeStride : nullptr;
     for (int h = 1 + t; h < 2048; h += 256) {
         const int lq = 31 - __clz(h);
-        const uint8_t cv0 = Cb[((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq))];
+        const uint8_t cv0 = (uint8_t)cget(Cb, ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq)));
         lv[h] = cv0;
         lvOld[h] = cv0;
     }
     const int64_t li = ((int64_t)1 << D) + base + t * 16;
-    uint4 cv = *(const uint4 *)(Cb + li);
+    uint32_t cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
     const uint4 tv = *(const uint4 *)(temp + (int64_t)brick * heapStride + li);
     const uint4 rv = *(const uint4 *)(rb.b[c.par] + (int64_t)brick * leafStride + base + t * 16);
-    uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
     int maxErr = 0;
     uint32_t pr = 0;            // pruned flags of my 16 leaves
@@ -776,11 +785,11 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int sh = (k & 3) * 8;
-        const int code = (cw[k >> 2] >> sh) & 255, tt = (tw[k >> 2] >> sh) & 255, rec = (rw[k >> 2] >> sh) & 255;
+        const int code = (cpk >> (2 * k)) & 3, tt = (tw[k >> 2] >> sh) & 255, rec = (rw[k >> 2] >> sh) & 255;
         const int err = rec > tt ? rec - tt : tt - rec;
         maxErr = err > maxErr ? err : maxErr;
         if (code == 0 && err < tol) {       // R.cpp:618-626
-            cw[k >> 2] |= 3u << sh;
+            cpk |= 3u << (2 * k);
             pr |= 1u << k;
         } else if (code == 3) pr |= 1u << k;
         // tokens this leaf emits when live: its code, then the grown branch (R.cpp:655-704)
@@ -798,13 +807,12 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         maxAfter = fe > maxAfter ? fe : maxAfter;     // encoder's own statistics after branch growth,
         l1After += (uint32_t)fe;                      // over every leaf (R.cpp:115-129)
     }
-    *(uint4 *)(Cb + li) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    *(uint32_t *)(Cb + (li >> 2)) = cpk;
     if (CR) {
-        uint4 q = *(const uint4 *)(CR + li);
-        uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+        uint32_t q = *(const uint32_t *)(CR + (li >> 2));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) if ((pr >> k) & 1u) qw[k >> 2] |= 3u << ((k & 3) * 8);   // M.cpp:864-865
-        *(uint4 *)(CR + li) = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+        for (int k = 0; k < 16; ++k) if ((pr >> k) & 1u) q |= 3u << (2 * k);   // M.cpp:864-865
+        *(uint32_t *)(CR + (li >> 2)) = q;
     }
     unsigned long long l1w = l1After;
     for (int o = 32; o > 0; o >>= 1) {
@@ -820,19 +828,19 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     // level D-1: 8 nodes per thread, children flags in registers
     {
         const int64_t ni = ((int64_t)1 << (D - 1)) + (base >> 1) + t * 8;
-        unsigned long long v = *(const unsigned long long *)(Cb + ni), vr = CR ? *(const unsigned long long *)(CR + ni) : 0ull;
+        uint32_t v = *(const uint16_t *)(Cb + (ni >> 2)), vr = CR ? *(const uint16_t *)(CR + (ni >> 2)) : 0u;   // 8 codes
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const bool both = ((pr >> (2 * k)) & 3u) == 3u;
-            const int code = (int)((v >> (8 * k)) & 255ull);
+            const int code = (int)((v >> (2 * k)) & 3u);
             const bool p = both && code == 0;
-            if (p) { v |= 3ull << (8 * k); vr |= 3ull << (8 * k); }
+            if (p) { v |= 3u << (2 * k); vr |= 3u << (2 * k); }
             const bool f3 = p || code == 3;
             fl[1][t * 8 + k] = (uint8_t)(f3 ? 1 : 0);
             cnt[1][t * 8 + k] = (uint16_t)(f3 ? 1 : 1 + tl[2 * k] + tl[2 * k + 1]);
         }
-        *(unsigned long long *)(Cb + ni) = v;
-        if (CR) *(unsigned long long *)(CR + ni) = vr;
+        *(uint16_t *)(Cb + (ni >> 2)) = (uint16_t)v;
+        if (CR) *(uint16_t *)(CR + (ni >> 2)) = (uint16_t)vr;
     }
     __syncthreads();
     // levels D-2 .. D-12 of this block (2047 codes) were fetched into LDS up front (one memory
@@ -853,11 +861,24 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         }
         __syncthreads();
     }
-    for (int h = 1 + t; h < 2048; h += 256) {
-        const int lq = 31 - __clz(h);               // depth below the block root
+    // write the block's levels back packed: levels with >= 4 nodes own whole bytes (plain stores of
+    // every byte); the top two levels (1 and 2 nodes) share bytes with neighbouring blocks -> atomic OR
+    for (int hb4 = 1 + t; hb4 < 512; hb4 += 256) {     // heap bytes 1..511 <-> heap nodes 4..2047
+        const int h = hb4 * 4;
+        const int lq = 31 - __clz(h);                   // depth below the block root (>= 2)
         const int64_t gi = ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq));
-        const uint8_t nv = lv[h];
-        if (nv != lvOld[h]) { Cb[gi] = nv; if (CR) CR[gi] = 3; }
+        const uint8_t pk = (uint8_t)(lv[h] | (lv[h + 1] << 2) | (lv[h + 2] << 4) | (lv[h + 3] << 6));
+        const uint8_t po = (uint8_t)(lvOld[h] | (lvOld[h + 1] << 2) | (lvOld[h + 2] << 4) | (lvOld[h + 3] << 6));
+        if (pk != po) {
+            Cb[gi >> 2] = pk;
+            if (CR) CR[gi >> 2] |= (uint8_t)(pk ^ po);   // newly pruned nodes: range code 3 as well (byte owned by me)
+        }
+    }
+    if (t >= 1 && t < 4 && lv[t] != lvOld[t]) {          // heap nodes 1..3: the block root and its children
+        const int lq = 31 - __clz(t);
+        const int64_t gi = ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (t - (1 << lq));
+        cset3(Cb, gi);
+        if (CR) cset3(CR, gi);
     }
 }
 
@@ -888,23 +909,23 @@ __device__ inline Owned owned_tokens(const uint8_t *__restrict__ Cb, const uint8
     o.nSpine = 0; o.nLeaf = 0; o.preDs = 0; o.aliveAtDs = 0; o.finalErr = -1;
     const int jmin = r ? D - (__ffs((int)r) - 1) : 0;
     bool alive = true;
-    if (jmin > 0) alive = Cb[((int64_t)1 << (jmin - 1)) + (r >> (D - jmin + 1))] != 3;
+    if (jmin > 0) alive = cget(Cb, ((int64_t)1 << (jmin - 1)) + (r >> (D - jmin + 1))) != 3;
     int j = jmin;
     for (; alive && j < D; ++j) {
         if (j == Ds) { o.preDs = o.nSpine; o.aliveAtDs = 1; }
         const int64_t ni = ((int64_t)1 << j) + (r >> (D - j));
-        int code = Cb[ni];
+        int code = cget(Cb, ni);
         o.spineBits |= (unsigned long long)code << (2 * o.nSpine);
-        if (CbR) o.spineBitsR |= (unsigned long long)CbR[ni] << (2 * o.nSpine);
+        if (CbR) o.spineBitsR |= (unsigned long long)cget(CbR, ni) << (2 * o.nSpine);
         o.nSpine++;
         if (code == 3) alive = false;
     }
     if (alive) {
         if (Ds == D) { o.preDs = o.nSpine; o.aliveAtDs = 1; }
         const int64_t li = ((int64_t)1 << D) + r;
-        int code = Cb[li];
+        int code = cget(Cb, li);
         o.leafBits = (uint32_t)code;
-        if (CbR) o.leafBitsR = CbR[li];
+        if (CbR) o.leafBitsR = (uint32_t)cget(CbR, li);
         o.nLeaf = 1;
         int t = Tb[li], rec = Rl[r];
         int tR = 0, recR = 0;
@@ -941,7 +962,7 @@ struct EmitArgs {
     const uint8_t *codes, *codesR, *temp, *tempR;
     ReconBufs rb, rbR;
     Ctrl *ctrls, *ctrlsR;
-    int64_t heapStride, leafStride;
+    int64_t heapStride, leafStride, codeStride;
     int D, maxDepth, tol, Ds, K;
     uint32_t *blockTot, *blockOff;
     unsigned long long *blockL1;   // per-block sum |recon - temp| after growth (reduced by k_emit_stats)
@@ -975,7 +996,7 @@ k_emit_count(EmitArgs a)
     __shared__ uint32_t shw[4];
     const int brick = blockIdx.y;
     const Ctrl &c = a.ctrls[brick];
-    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
     const uint32_t n = 1u << a.D;
@@ -1060,10 +1081,10 @@ k_emit_write(EmitArgs a)
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
     const bool mr = a.codesR != nullptr;
-    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
-    const uint8_t *CbR = mr ? a.codesR + (int64_t)brick * a.heapStride : nullptr;
+    const uint8_t *CbR = mr ? a.codesR + (int64_t)brick * a.codeStride : nullptr;
     const uint8_t *TbR = mr ? a.tempR + (int64_t)brick * a.heapStride : nullptr;
     const uint8_t *RlR = mr ? a.rbR.b[a.ctrlsR[brick].par] + (int64_t)brick * a.leafStride : nullptr;
     const uint8_t *dmapR = mr ? a.ctrlsR[brick].distanceMap : nullptr;
@@ -1093,7 +1114,7 @@ k_emit_write(EmitArgs a)
         const uint32_t s = r >> a.K;
         int val = c.distanceMap[0];              // root scalar (R.cpp:743)
         for (int j = 1; j <= a.Ds; ++j) {
-            int code = Cb[((int64_t)1 << j) + (s >> (a.Ds - j))];
+            int code = cget(Cb, ((int64_t)1 << j) + (s >> (a.Ds - j)));
             val = apply_code(val, code, c.distanceMap[j]); // pruned descendants carry code 3: unchanged
         }
         a.idxOff[(int64_t)brick * a.nIdx + s] = o.aliveAtDs ? g0 + lo + (uint32_t)o.preDs : VR_IDX_DEAD;
@@ -1140,9 +1161,12 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
     Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0; Q.maxErr = 0; Q.l1 = 0;
     const uint32_t lr = r0 & 1023u;                                  // rank inside the block
     // every global load is issued before any is looked at: one memory latency, no dependent chain
-    const int quadCode = Cb[((int64_t)1 << (D - 2)) + (r0 >> 2)];
-    const uint32_t pair = *(const uint16_t *)(Cb + ((int64_t)1 << (D - 1)) + (r0 >> 1));
-    const uint32_t cl = *(const uint32_t *)(Cb + ((int64_t)1 << D) + r0);
+    const int quadCode = cget(Cb, ((int64_t)1 << (D - 2)) + (r0 >> 2));
+    const uint32_t pairB = Cb[(((int64_t)1 << (D - 1)) + (r0 >> 1)) >> 2];          // 4 packed depth-(D-1) codes
+    const uint32_t pk2 = (pairB >> (((r0 >> 1) & 3u) * 2u)) & 15u;                   // mine: two of them
+    const uint32_t pair = (pk2 & 3u) | ((pk2 >> 2) << 8);
+    const uint32_t clb = Cb[(((int64_t)1 << D) + r0) >> 2];                          // my four leaf codes = one byte
+    const uint32_t cl = (clb & 3u) | (((clb >> 2) & 3u) << 8) | (((clb >> 4) & 3u) << 16) | (((clb >> 6) & 3u) << 24);
     const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
     const uint32_t rl = *(const uint32_t *)(Rl + r0);
     bool alive;
@@ -1214,7 +1238,7 @@ k_block_alive(EmitArgs a, int64_t nblk)
     const int brick = blockIdx.y;
     const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blk >= nblk) return;
-    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *dmap = a.ctrls[brick].distanceMap;
     const int dl = a.D - 10;
     bool alive = true;
@@ -1225,7 +1249,7 @@ k_block_alive(EmitArgs a, int64_t nblk)
     const int jmin = r0 ? a.D - (__ffs((int)r0) - 1) : 0;     // first spine depth of rank r0 (<= dl)
     bool pathAlive = true;
     for (int j = 0; j < dl; ++j) {
-        const int code = Cb[((int64_t)1 << j) + (blk >> (dl - j))];
+        const int code = cget(Cb, ((int64_t)1 << j) + (blk >> (dl - j)));
         if (j > 0) val = apply_code(val, code, dmap[j]);
         if (pathAlive && j >= jmin) { spine |= (unsigned long long)code << (2 * nsp); ++nsp; }
         if (code == 3 && pathAlive) {
@@ -1251,7 +1275,7 @@ k_emit4(EmitArgs a)
     __shared__ uint32_t W[WRITE ? EMIT4_LDS_WORDS : 1];
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
-    const uint8_t *Cb = a.codes + (int64_t)brick * a.heapStride;
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
     const uint32_t r0 = blockIdx.x * EMIT4_RANKS + threadIdx.x * 4;
@@ -1272,7 +1296,7 @@ k_emit4(EmitArgs a)
     if (threadIdx.x >= 1) {
         const int t = threadIdx.x;                    // heap index inside the block: 1 .. 255
         const int l = 31 - __clz(t);
-        inner[t] = Cb[((int64_t)1 << (a.D - 10 + l)) + (((int64_t)blockIdx.x) << l) + (t - (1 << l))];
+        inner[t] = (uint8_t)cget(Cb, ((int64_t)1 << (a.D - 10 + l)) + (((int64_t)blockIdx.x) << l) + (t - (1 << l)));
     }
     if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
     __syncthreads();
@@ -1312,9 +1336,8 @@ k_emit4(EmitArgs a)
         const uint32_t lr = r0 & 1023u;
         for (int j = a.D - 10; j <= a.Ds; ++j) {
             const int l = j - (a.D - 10);
-            const int code = j == a.D - 2 ? Cb[((int64_t)1 << j) + (r0 >> 2)]
-                           : (j == a.D - 1 ? Cb[((int64_t)1 << j) + (r0 >> 1)]
-                           : (j == a.D ? Cb[((int64_t)1 << j) + r0] : inner[(1 << l) + (lr >> (a.D - j))]));
+            const int code = j >= a.D - 2 ? cget(Cb, ((int64_t)1 << j) + (r0 >> (a.D - j)))
+                                          : inner[(1 << l) + (lr >> (a.D - j))];
             val = j == 0 ? val : apply_code(val, code, c.distanceMap[j]);
         }
         a.idxOff[(int64_t)brick * a.nIdx + sidx] = Q.aliveAtDs ? g0 + lo + (uint32_t)Q.preDs : VR_IDX_DEAD;
@@ -1354,7 +1377,7 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
     hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl);
     if (bs->maxEpochs <= 0) { // the loop never runs: tree.resize() / recon.resize() zero-fill is the result
         for (int i = 0; i < 3; ++i) hipMemsetAsync(s.recon[i], 0, (size_t)B * bs->leafStride, st);
-        hipMemsetAsync(s.codes, 0, (size_t)B * bs->heapStride, st);
+        hipMemsetAsync(s.codes, 0, (size_t)B * bs->codeStride, st);
     }
     for (int d = 0; d <= D; ++d) {
         const int64_t n = (int64_t)1 << d;
@@ -1374,10 +1397,10 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
                 hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
             hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, guarded, s.ctrl, s.temp,
                                bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
         }
@@ -1474,18 +1497,18 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     int pruneFrom = D - 1;
     if (D >= 12) {
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
-                           bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
-                           bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
+                           bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
+                           bs->codeStride, rb, bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
                            bs->nEmitBlk,    // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
                            (!mr && bs->K >= 2) ? bs->blockL1 : nullptr);
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
-                           bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride, rb,
-                           bs->leafStride, bs->maxDepth, bs->blockL1, bs->nEmitBlk);
+                           bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
+                           bs->codeStride, rb, bs->leafStride, bs->maxDepth, bs->blockL1, bs->nEmitBlk);
     for (int d = pruneFrom; d >= 0; --d)
         hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.codes,
-                           mr ? bs->rng.codes : nullptr, bs->heapStride);
+                           mr ? bs->rng.codes : nullptr, bs->codeStride);
     hipLaunchKernelGGL(k_fix_chain_distances, dim3(B), dim3(64), 0, st, D, bs->maxDepth, bs->mid.ctrl,
                        mr ? bs->rng.ctrl : nullptr);
     hipEventRecord(bs->ev[3], st);
@@ -1496,7 +1519,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.temp = bs->mid.temp; a.tempR = mr ? bs->rng.temp : nullptr;
     a.rb = rb; a.rbR = rbR;
     a.ctrls = bs->mid.ctrl; a.ctrlsR = mr ? bs->rng.ctrl : nullptr;
-    a.heapStride = bs->heapStride; a.leafStride = bs->leafStride;
+    a.heapStride = bs->heapStride; a.leafStride = bs->leafStride; a.codeStride = bs->codeStride;
     a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
     a.blockL1 = bs->blockL1;
