@@ -484,7 +484,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 __global__ void __launch_bounds__(256)
-k_fill16(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
+k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
          int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
 {
     __shared__ unsigned long long shm[4], shp[4];
@@ -498,6 +498,9 @@ k_fill16(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restri
     const int dist = (int)(uint8_t)c.currentDistance;
     const int distM = (int)(uint8_t)fmax(0.0, c.currentDistance - 1.0);   // R.cpp:334
     const int distP = (int)(uint8_t)fmin(255.0, c.currentDistance + 1.0);
+    // the central difference (R.cpp:333-362) only steers a FOLLOWING epoch: in the last one its result is
+    // never read (VolumeKdtree.cpp:333 skips it outright), so the two extra evaluations are not made
+    const bool needDF = c.epoch + 1 < maxEpochs;
     const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
     const uint4 tv = *(const uint4 *)(T + i0);
     const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
@@ -511,9 +514,11 @@ k_fill16(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restri
         cpk |= (uint32_t)e.code << (2 * k);
         rw[k >> 2] |= (uint32_t)e.recon << ((k & 3) * 8);
         e0 += (uint32_t)(e.err * e.err);
-        const int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
-        em += (uint32_t)(a * a);
-        ep += (uint32_t)(b * b);
+        if (needDF) {
+            const int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
+            em += (uint32_t)(a * a);
+            ep += (uint32_t)(b * b);
+        }
     }
     *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
     *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
@@ -1396,7 +1401,7 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
-                hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, s.ctrl, s.temp,
+                hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, bs->maxEpochs, s.ctrl, s.temp,
                                    s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
