@@ -189,10 +189,12 @@ def main():
     # decode kernel roofline: algorithmic bytes = V + ceil(numActiveNodes/4) + (maxTreeDepth+1) per brick
     alg = 0
     tokens = 0
+    n_const = 0                       # bricks of a single value: encoded in closed form (k_const_finish)
     for b in range(B):
         inf = bs.info(b)
         alg += V + inf["tree_bytes"] + inf["max_tree_depth"] + 1
         tokens += inf["num_active_nodes"]
+        n_const += inf["num_active_nodes"] <= 3
     dec_avg_s = sum(dec_ms) / len(dec_ms) / 1e3
     achieved = alg / dec_avg_s / 1e9
     # HBM traffic of the decode launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
@@ -217,6 +219,7 @@ def main():
                       "maxEpochs %d, VolumeKdtree build + levelCut" % (gdims[0], gdims[1], gdims[2], B, bdims[0],
                                                                          bdims[1], bdims[2], args.kind, args.tolerance,
                                                                          args.max_epochs),
+                      "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
            "encode_ms": round(sum(enc_ms) / len(enc_ms), 3), "decode_ms": round(dec_avg_s * 1e3, 3),

@@ -83,6 +83,32 @@ def test_degenerate_volumes(vr, oracle):
     check_case(vr, oracle, oracle.gen_sphere(16, 7), 1, 0)            # maxEpochs = 0
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 1), (8, 8, 8), (16, 32, 64), (64, 64, 64)])
+def test_constant_brick_closed_form(vr, oracle, shape):
+    """Constant bricks take k_const_finish (tolerance >= 1, maxEpochs >= 1) or the general path
+    (tolerance 0 / maxEpochs 0): both must equal the oracle, alone and inside a mixed batch."""
+    for v in (0, 1, 128, 255):
+        for tol, ep in ((1, 2), (6, 5), (1, 1), (0, 2), (3, 0)):
+            check_case(vr, oracle, np.full(shape, v, np.uint8), tol, ep)
+    z, y, x = shape
+    rng = np.random.default_rng(9)
+    vols = [np.full(shape, 0, np.uint8), rng.integers(0, 256, shape, dtype=np.uint8), np.full(shape, 77, np.uint8),
+            rm_like(shape), np.full(shape, 255, np.uint8)]
+    bs = vr.BrickSet(len(vols), (x, y, z), 1, 2)
+    bs.build(np.stack(vols))
+    dec = bs.decode().cpu().numpy().reshape(len(vols), z, y, x)
+    D = bs.info(0)["orig_tree_depth"]
+    cut = bs.decode(cut_depth=max(D - 3, 0)).cpu().numpy().reshape(len(vols), z, y, x)
+    for i, v in enumerate(vols):
+        ref = oracle.OracleTree(v.copy(), tolerance=1, max_epochs=2).build()
+        assert bs.info(i)["num_active_nodes"] == ref.numActiveNodes
+        assert np.array_equal(bs.tree(i), ref.tree)
+        assert list(bs.distance_map(i)) == list(ref.distanceMap)
+        assert np.array_equal(dec[i], ref.levelCut())
+        assert np.array_equal(cut[i], ref.levelCutProgressive(max(D - 3, 0)))
+        assert bs.info(i)["num_reverts"] == ref.numReverts
+
+
 def test_guarded_variant_same_bytes(vr, oracle):
     vol = oracle.gen_sphere(32, 7)
     a = vr.BrickSet(1, (32, 32, 32), 1, 3, 0).build(vol.copy())

@@ -60,6 +60,8 @@ struct Ctrl {
     int32_t estSeg;          // estimator: next segment to verify
     int32_t estDone;         // estimator: level finished
     int32_t emitOverflow;    // emit refused to write past the stream buffer (internal error)
+    int32_t constBrick;      // every voxel of the brick has the same value: closed-form result (k_const_finish)
+    int32_t constVal;
     uint8_t distanceMap[VR_MAX_DEPTH + 8];
 };
 

@@ -164,10 +164,18 @@ struct ReconBufs { uint8_t *b[3]; };
 
 __device__ inline int phys_buf(const Ctrl &c, int role) { return role == 0 ? c.ra : c.rb; }
 
-__global__ void k_ctrl_init(Ctrl *ctrls)
+// rootMin/rootMax: the pyramid's (min, max) of each brick's root, or null.  A brick whose voxels are
+// all equal has a closed-form encoding (k_const_finish); every later kernel skips it.
+__global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *rootMax, int64_t mmStride)
 {
     Ctrl &c = ctrls[blockIdx.x];
     if (threadIdx.x) return;
+    c.constBrick = 0; c.constVal = 0;
+    if (rootMin) {
+        const int mn = rootMin[(int64_t)blockIdx.x * mmStride], mx = rootMax[(int64_t)blockIdx.x * mmStride];
+        c.constBrick = mn == mx ? 1 : 0;
+        c.constVal = mn;
+    }
     c.currentDistance = c.currentError = c.currentDF = c.currentStepSize = 0.0; // defect C-1 pinned to zero
     c.previousDistance = c.previousError = c.previousDF = c.previousStepSize = 0.0;
     c.errMinus = c.errPlus = 0;
@@ -274,6 +282,7 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
+    if (c.constBrick) return;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
     const uint32_t n = 1u << d;
@@ -299,7 +308,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     const Ctrl &c = ctrls[brick];
     const uint32_t n = 1u << d;
     const uint32_t seg = EST_HEAD / EST_SEG + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c.estDone || seg < (uint32_t)c.estSeg || seg >= n / EST_SEG) return;
+    if (c.constBrick || c.estDone || seg < (uint32_t)c.estSeg || seg >= n / EST_SEG) return;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + (size_t)seg * EST_SEG + lane * 16;
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride + (((size_t)seg * EST_SEG + lane * 16) >> 1);
     const uint4 tv = *(const uint4 *)T;
@@ -359,7 +368,7 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
     const uint32_t n = 1u << d, nseg = n / EST_SEG;
     const EstSummary *sm = summ + (int64_t)brick * summStride;
-    if (c.estDone) return;
+    if (c.constBrick || c.estDone) return;
     unsigned long long S = c.estS;
     uint32_t C = c.estC;
     const int Tbase = c.estTbase;
@@ -432,7 +441,7 @@ k_fill(int d, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict
     __shared__ unsigned long long sh[4];
     const int brick = blockIdx.y;
     Ctrl &c = ctrls[brick];
-    if (!c.fillThisEpoch) return;
+    if (c.constBrick || !c.fillThisEpoch) return;
     const uint32_t n = 1u << d;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
     uint8_t *Cb = codes + (int64_t)brick * codeStride;
@@ -490,7 +499,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
     Ctrl &c = ctrls[brick];
-    if (!c.fillThisEpoch) return;
+    if (c.constBrick || !c.fillThisEpoch) return;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
     uint8_t *Cd = codes + (int64_t)brick * codeStride + ((int64_t)1 << (d - 2));   // packed: 4 codes per byte
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
@@ -587,6 +596,7 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
+    if (c.constBrick) return;
     const uint32_t n = 1u << d;
     const bool ending = c.active && c.fillThisEpoch;
     double s = c.currentError;
@@ -673,6 +683,7 @@ __global__ void k_level_end(int d, Ctrl *ctrls)
 {
     if (threadIdx.x) return;
     Ctrl &c = ctrls[blockIdx.x];
+    if (c.constBrick) return;
     c.distanceMap[d] = (uint8_t)c.currentDistance;
     int finalRole = c.pendingEqual ? c.prev : c.cur;
     int finalPhys = phys_buf(c, finalRole);
@@ -696,6 +707,7 @@ k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint
     __shared__ unsigned long long shl[4];
     const int brick = blockIdx.y;
     Ctrl &c = ctrls[brick];
+    if (c.constBrick) return;
     const uint32_t n = 1u << D;
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
     int err = 0, fe = 0;
@@ -739,9 +751,10 @@ k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint
 }
 
 __global__ void __launch_bounds__(256)
-k_prune_level(int d, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRange, int64_t codeStride)
+k_prune_level(int d, const Ctrl *ctrls, uint8_t *__restrict__ codes, uint8_t *__restrict__ codesRange, int64_t codeStride)
 {
     const int brick = blockIdx.y;
+    if (ctrls[brick].constBrick) return;
     const uint32_t n = 1u << d;
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
@@ -768,6 +781,7 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     __shared__ uint8_t lv[2048], lvOld[2048];     // codes of the block's nodes at depths D-12 .. D-2, heap order
     const int brick = blockIdx.y, t = threadIdx.x;
     Ctrl &c = ctrls[brick];
+    if (c.constBrick) return;
     const uint32_t base = blockIdx.x << 12;
     uint8_t *Cb = codes + (int64_t)brick * codeStride;
     uint8_t *CR = codesRange ? codesRange + (int64_t)brick * codeStride : nullptr;
@@ -1001,6 +1015,7 @@ k_emit_count(EmitArgs a)
     __shared__ uint32_t shw[4];
     const int brick = blockIdx.y;
     const Ctrl &c = a.ctrls[brick];
+    if (c.constBrick) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
@@ -1024,6 +1039,7 @@ k_emit_scan(EmitArgs a, int64_t nblk)
     __shared__ uint32_t shw[16];
     __shared__ uint32_t carrySh;
     const int brick = blockIdx.x;
+    if (a.ctrls[brick].constBrick) return;
     const uint32_t *in = a.blockTot + (int64_t)brick * a.nEmitBlk;
     uint32_t *out = a.blockOff + (int64_t)brick * a.nEmitBlk;
     if (threadIdx.x == 0) carrySh = 0;
@@ -1052,7 +1068,7 @@ k_emit_zero(EmitArgs a, int64_t nblk)
 {
     const int brick = blockIdx.y;
     int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (blk >= nblk) return;
+    if (blk >= nblk || a.ctrls[brick].constBrick) return;
     uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blk];
     uint32_t tot = a.blockTot[(int64_t)brick * a.nEmitBlk + blk];
     uint32_t *W = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
@@ -1085,6 +1101,7 @@ k_emit_write(EmitArgs a)
     __shared__ uint32_t W[EMIT_LDS_WORDS], WR[EMIT_LDS_WORDS];
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
+    if (c.constBrick) return;
     const bool mr = a.codesR != nullptr;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
@@ -1242,7 +1259,7 @@ k_block_alive(EmitArgs a, int64_t nblk)
 {
     const int brick = blockIdx.y;
     const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (blk >= nblk) return;
+    if (blk >= nblk || a.ctrls[brick].constBrick) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *dmap = a.ctrls[brick].distanceMap;
     const int dl = a.D - 10;
@@ -1280,6 +1297,7 @@ k_emit4(EmitArgs a)
     __shared__ uint32_t W[WRITE ? EMIT4_LDS_WORDS : 1];
     const int brick = blockIdx.y;
     Ctrl &c = a.ctrls[brick];
+    if (c.constBrick) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
     const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
@@ -1363,6 +1381,7 @@ k_emit_stats(EmitArgs a, int64_t nblk)
 {
     __shared__ unsigned long long sh[16];
     const int brick = blockIdx.x;
+    if (a.ctrls[brick].constBrick) return;
     unsigned long long v = 0;
     for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) v += a.blockL1[(int64_t)brick * a.nEmitBlk + i];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1371,15 +1390,42 @@ k_emit_stats(EmitArgs a, int64_t nblk)
     if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += sh[i]; a.ctrls[brick].statL1 = t; }
 }
 
+// Closed form for a brick of one value v (tolerance >= 1, maxEpochs >= 1, D >= 1): the root's
+// distance is v (running mean of the single mismatch |0 - v|), its code is "add" (or "keep" for
+// v = 0), every other node reproduces its parent exactly (distance 0, code 0) and is pruned, so
+// the stream is [1][3][3] (or [3] for v = 0), all statistics are 0 and every decode-index entry
+// is "dead" with scalar v.  Identical to what the general path produces (tests compare both with
+// the oracle); it just skips ~all work for the constant regions of a volume.
+__global__ void __launch_bounds__(256)
+k_const_finish(int D, Ctrl *ctrls, uint8_t *tree, int64_t treeCap, uint32_t *idxOff, uint8_t *idxVal, int64_t nIdx)
+{
+    const int brick = blockIdx.y;
+    Ctrl &c = ctrls[brick];
+    if (!c.constBrick) return;
+    const int v = c.constVal;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int d = 0; d <= D; ++d) c.distanceMap[d] = d == 0 ? (uint8_t)v : 0;
+        c.numActive = v ? 3 : 1;
+        *(uint32_t *)(tree + (int64_t)brick * treeCap) = v ? 0x3Du : 0x03u;
+        c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0; c.statL1 = 0; c.emitOverflow = 0;
+    }
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < nIdx) {
+        idxOff[(int64_t)brick * nIdx + s] = VR_IDX_DEAD;
+        idxVal[(int64_t)brick * nIdx + s] = (uint8_t)v;
+    }
+}
+
 // ------------------------------------------------------------ host driver ----
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st)
+static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint8_t *rootMin, const uint8_t *rootMax,
+                            int64_t mmStride)
 {
     const int D = bs->D, B = bs->B;
     ReconBufs rb{{s.recon[0], s.recon[1], s.recon[2]}};
     const int guarded = bs->variant != 0; // GUARDED and MIDRANGE both carry the :333/:340 guard
-    hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl);
+    hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl, rootMin, rootMax, mmStride);
     if (bs->maxEpochs <= 0) { // the loop never runs: tree.resize() / recon.resize() zero-fill is the result
         for (int i = 0; i < 3; ++i) hipMemsetAsync(s.recon[i], 0, (size_t)B * bs->leafStride, st);
         hipMemsetAsync(s.codes, 0, (size_t)B * bs->codeStride, st);
@@ -1438,6 +1484,8 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     const int D = bs->D, B = bs->B;
     const bool mr = bs->variant == 2;
     hipEventRecord(bs->ev[0], st);
+    const uint8_t *rootMinP = nullptr, *rootMaxP = nullptr;   // where the last pyramid round leaves each brick's root (min,max)
+    const int64_t rootStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
     // ---- BUILD: pyramid.  Bottom 12 levels by k_pyramid12 when x-runs of 16 voxels exist,
     // the rest (and small / thin bricks) in rounds of <= 10 levels.
     {
@@ -1469,6 +1517,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                                oStride);
             dLeaf = D - 12;
             inMin = bs->mmMin[0]; inMax = bs->mmMax[0]; inStride = oStride;
+            rootMinP = inMin; rootMaxP = inMax;
             round = 1;
         }
         while (dLeaf > 0 || round == 0) {
@@ -1484,6 +1533,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                                    inMin, inMax, inStride, bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr,
                                    oMin, oMax, oStride);
             dLeaf -= L;
+            rootMinP = oMin; rootMaxP = oMax;
             if (dLeaf == 0) break;
             inMin = oMin; inMax = oMax; inStride = oStride;
             ++round;
@@ -1492,8 +1542,10 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipEventRecord(bs->ev[1], st);
     dbg_sync(st, "pyramid");
     // ---- COMPRESS
-    compress_stream(bs, bs->mid, st);
-    if (mr) compress_stream(bs, bs->rng, st);
+    // constant bricks take the closed form (VolumeKdtree streams; needs the leaf prune and an epoch to exist)
+    const bool constOk = !mr && bs->maxEpochs >= 1 && bs->tolerance >= 1 && D >= 1;
+    compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride);
+    if (mr) compress_stream(bs, bs->rng, st, nullptr, nullptr, 0);
     hipEventRecord(bs->ev[2], st);
     dbg_sync(st, "compress");
     // ---- PRUNE
@@ -1512,7 +1564,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
                            bs->codeStride, rb, bs->leafStride, bs->maxDepth, bs->blockL1, bs->nEmitBlk);
     for (int d = pruneFrom; d >= 0; --d)
-        hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.codes,
+        hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.ctrl, bs->mid.codes,
                            mr ? bs->rng.codes : nullptr, bs->codeStride);
     hipLaunchKernelGGL(k_fix_chain_distances, dim3(B), dim3(64), 0, st, D, bs->maxDepth, bs->mid.ctrl,
                        mr ? bs->rng.ctrl : nullptr);
@@ -1542,6 +1594,8 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, nblk);
+    hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.tree,
+                       bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
     hipEventRecord(bs->ev[4], st);
     dbg_sync(st, "emit_write");
     return launch_status("encode");
