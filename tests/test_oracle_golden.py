@@ -96,3 +96,26 @@ def test_oracle_properties(oracle):
     v = rng.integers(0, 256, (5, 6, 12), dtype=np.uint8)
     t = O.OracleTree(v.copy(), tolerance=1, max_epochs=2).build()
     t.levelCut()
+
+
+def test_encode_node_closed_form_exhaustive():
+    """The packed HIP kernels (kd_common.h enc_pair*) use a reduced form of encodeNode (R.cpp:457-502):
+    the candidate on the far side of the parent never beats "keep" and the clamp only shortens the
+    step.  Checked here over every (truth, parent, distance)."""
+    t = np.arange(256, dtype=np.int32)[:, None, None]
+    p = np.arange(256, dtype=np.int32)[None, :, None]
+    d = np.arange(256, dtype=np.int32)[None, None, :]
+    none = np.abs(p - t) + 0 * d
+    add = np.minimum(p + d, 255); ae = np.abs(add - t)
+    sub = np.maximum(p - d, 0); se = np.abs(sub - t)
+    m = np.minimum(np.minimum(none, ae), se)
+    code = np.where(m == none, 0, np.where(m == ae, 1, 2))
+    recon = np.where(m == none, p + 0 * d, np.where(m == ae, add, sub))
+    pd = np.abs(t - p) + 0 * d
+    up = (t > p) + 0 * d
+    h = np.where(up, 255 - t, t) + 0 * d
+    x = np.minimum(d - pd, h)
+    take = np.abs(x) < pd
+    assert np.array_equal(m, np.minimum(pd, np.abs(x)))
+    assert np.array_equal(code, np.where(take, np.where(up, 1, 2), 0))
+    assert np.array_equal(recon, np.where(take, np.where(up, t + x, t - x), p + 0 * d))

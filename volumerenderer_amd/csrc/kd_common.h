@@ -84,6 +84,45 @@ __host__ __device__ inline Enc encode_node(int t, int p, int d)
     return e;
 }
 
+#ifdef __HIPCC__
+// Two nodes per VALU instruction (packed 16-bit lanes).  encode_node reduces to
+//     pd = |t-p|, up = t>p, h = up ? 255-t : t, x = min(d-pd, h), take = |x| < pd
+//     err = min(pd,|x|), code = take ? (up ? 1 : 2) : 0, recon = take ? (up ? t+x : t-x) : p
+// (the candidate on the far side of the parent never beats "keep", the clamp only ever shortens
+// the step: checked exhaustively over all (t,p,d) in tests/test_oracle_golden.py).
+typedef short vr_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short vr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vr_s16x2 pk_s(uint32_t v) { return __builtin_bit_cast(vr_s16x2, v); }
+__device__ __forceinline__ uint32_t pk_u(vr_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ vr_s16x2 pk_abs(vr_s16x2 x) { return __builtin_elementwise_max(x, (vr_s16x2)(0) - x); }
+__device__ __forceinline__ uint32_t pk_sumsq(vr_s16x2 e, uint32_t acc)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(vr_u16x2, e), __builtin_bit_cast(vr_u16x2, e), acc, false);
+}
+struct EncPair { vr_s16x2 T2, P2, pd, h; uint32_t up; };   // up: 0xFFFF per lane where t > p
+// the sibling pair (bytes 2*tsel, 2*tsel+1 of tword) and their shared parent (byte psel of pword)
+__device__ __forceinline__ EncPair enc_pair(uint32_t tword, int tsel, uint32_t pword, int psel)
+{
+    EncPair c;
+    const uint32_t T2 = __builtin_amdgcn_perm(0, tword, tsel ? 0x0c030c02u : 0x0c010c00u);
+    const uint32_t P2 = __builtin_amdgcn_perm(0, pword, 0x0c000c00u | (uint32_t)psel | ((uint32_t)psel << 16));
+    c.T2 = pk_s(T2); c.P2 = pk_s(P2);
+    const vr_s16x2 diff = c.T2 - c.P2, nd = (vr_s16x2)(0) - diff;
+    c.pd = __builtin_elementwise_max(diff, nd);
+    c.up = pk_u(nd >> 15);
+    c.h = pk_s(T2 ^ (c.up & 0x00FF00FFu));
+    return c;
+}
+__device__ __forceinline__ vr_s16x2 enc_pair_x(const EncPair &c, uint32_t d2)   // d2 = dist * 0x10001
+{
+    return __builtin_elementwise_min(pk_s(d2) - c.pd, c.h);
+}
+__device__ __forceinline__ vr_s16x2 enc_pair_err(const EncPair &c, uint32_t d2)
+{
+    return __builtin_elementwise_min(c.pd, pk_abs(enc_pair_x(c, d2)));
+}
+#endif
+
 // decoder step (R.cpp:783-787): child scalar from parent scalar and the child's code
 __host__ __device__ inline int apply_code(int v, int code, int dist)
 {

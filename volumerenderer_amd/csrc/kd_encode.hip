@@ -514,21 +514,27 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     const uint4 tv = *(const uint4 *)(T + i0);
     const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
-    uint32_t cpk = 0, rw[4] = {0, 0, 0, 0};
-    uint32_t e0 = 0, em = 0, ep = 0;
+    const uint32_t d2 = (uint32_t)dist * 0x10001u, dm2 = (uint32_t)distM * 0x10001u, dp2 = (uint32_t)distP * 0x10001u;
+    uint32_t e0 = 0, em = 0, ep = 0, wa = 0, wb = 0, rw[4], rprev = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int t = (tw[k >> 2] >> ((k & 3) * 8)) & 255, p = (pw[k >> 3] >> (((k >> 1) & 3) * 8)) & 255;
-        const Enc e = encode_node(t, p, dist);
-        cpk |= (uint32_t)e.code << (2 * k);
-        rw[k >> 2] |= (uint32_t)e.recon << ((k & 3) * 8);
-        e0 += (uint32_t)(e.err * e.err);
+    for (int j = 0; j < 8; ++j) {                        // sibling pair j: nodes 2j, 2j+1, parent byte j
+        const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
+        const vr_s16x2 x = enc_pair_x(c, d2), ax = pk_abs(x);
+        e0 = pk_sumsq(__builtin_elementwise_min(c.pd, ax), e0);
+        const uint32_t take = pk_u((ax - c.pd) >> 15);                 // 0xFFFF per lane where |x| < pd
+        const uint32_t code2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));   // up ? 1 : 2 (per-lane wrap)
+        if (j < 4) wa |= code2 << (4 * j); else wb |= code2 << (4 * (j - 4));
+        const uint32_t dn = ~c.up;
+        const vr_s16x2 r = c.T2 + (pk_s(pk_u(x) ^ dn) - pk_s(dn));    // up ? t + x : t - x
+        const uint32_t rec = (take & pk_u(r)) | (~take & pk_u(c.P2));
+        if (j & 1) rw[j >> 1] = __builtin_amdgcn_perm(rec, rprev, 0x06040200u); else rprev = rec;
         if (needDF) {
-            const int a = encode_node(t, p, distM).err, b = encode_node(t, p, distP).err;
-            em += (uint32_t)(a * a);
-            ep += (uint32_t)(b * b);
+            em = pk_sumsq(enc_pair_err(c, dm2), em);
+            ep = pk_sumsq(enc_pair_err(c, dp2), ep);
         }
     }
+    // even nodes sit at bits 4j, odd ones at 16+4j: fold to 2 bits per node
+    const uint32_t cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
     *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
     *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
     const unsigned long long s0 = wave_sum_u64(e0), sm = wave_sum_u64(em), sp = wave_sum_u64(ep);
