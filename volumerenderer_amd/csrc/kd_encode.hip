@@ -300,6 +300,38 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
     }
 }
 
+// wave64 inclusive scans on the DPP network (row shifts inside 16-lane rows, then the two row
+// broadcasts): six VALU instructions instead of six LDS-crossbar shuffles.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_add_dpp(uint32_t v)
+{
+    v += dpp_u32<0x111, 0xf>(0, v);   // row_shr:1
+    v += dpp_u32<0x112, 0xf>(0, v);   // row_shr:2
+    v += dpp_u32<0x114, 0xf>(0, v);   // row_shr:4
+    v += dpp_u32<0x118, 0xf>(0, v);   // row_shr:8
+    v += dpp_u32<0x142, 0xa>(0, v);   // row_bcast:15 into rows 1, 3
+    v += dpp_u32<0x143, 0xc>(0, v);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32_dpp(int v)   // result valid in lane 63 (returned via readlane)
+{
+    const uint32_t I = 0x80000000u;
+    v = max(v, (int)dpp_u32<0x111, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x112, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x114, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x118, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x142, 0xa>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x143, 0xc>(I, (uint32_t)v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One wave per segment, 16 consecutive nodes per lane as two chains of 8 (nodes k and k+8 share a
+// packed 16-bit register pair).  With h = (t>p ? 255-t : t) the reference's "forced" cases are
+// pd > h, so under the hypothesis floor(S/(2C+1)) == Th node k counts  <=>  pd_k > min(Th, h_k).
 __global__ void __launch_bounds__(256)
 k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
            int64_t leafStride, EstSummary *__restrict__ summ, int64_t summStride)
@@ -313,20 +345,22 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride + (((size_t)seg * EST_SEG + lane * 16) >> 1);
     const uint4 tv = *(const uint4 *)T;
     const uint2 pv = *(const uint2 *)P;
-    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
-    int pd[16];
-    uint32_t forcedMask = 0;
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w};
+    vr_s16x2 pd[8], h[8];
+    uint32_t anyPd = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        int t = (tw[k >> 2] >> ((k & 3) * 8)) & 255, p = (pw[k >> 3] >> (((k >> 1) & 3) * 8)) & 255;
-        pd[k] = p > t ? p - t : t - p;
-        if ((t > p && 2 * t - p > 255) || (t < p && 2 * t < p)) forcedMask |= 1u << k;
+    for (int k = 0; k < 8; ++k) {
+        // lanes: (node k, node k+8); their parents are bytes k>>1 of the two parent words
+        const uint32_t bsel = (uint32_t)(k & 3), psel = (uint32_t)(k >> 1);
+        const uint32_t T2 = __builtin_amdgcn_perm(tw[(k >> 2) + 2], tw[k >> 2], 0x0c040c00u | bsel | (bsel << 16));
+        const uint32_t P2 = __builtin_amdgcn_perm(pv.y, pv.x, 0x0c040c00u | psel | (psel << 16));
+        const vr_s16x2 diff = pk_s(T2) - pk_s(P2), nd = (vr_s16x2)(0) - diff;
+        pd[k] = __builtin_elementwise_max(diff, nd);
+        h[k] = pk_s(T2 ^ (pk_u(nd >> 15) & 0x00FF00FFu));
+        anyPd |= pk_u(pd[k]);
     }
     const int Tbase = c.estTbase;
     EstSummary *out = summ + (int64_t)brick * summStride + seg;
-    uint32_t anyPd = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) anyPd |= (uint32_t)pd[k];
     if (__ballot(anyPd != 0) == 0ull) {      // parents reproduce the truths exactly (constant regions): nothing counts
         if (lane < nc) { out->sumS[lane] = 0; out->sumC[lane] = 0; out->A[lane] = 0; out->B[lane] = 0; }
         return;
@@ -334,27 +368,34 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
 #pragma unroll 1
     for (int ci = 0; ci < nc; ++ci) {
         const int Th = Tbase + ci;
-        int s = 0, cc = 0, a = INT32_MIN, b = INT32_MAX;
+        const vr_s16x2 Th2 = pk_s((uint32_t)Th * 0x10001u), w2 = pk_s((uint32_t)(2 * Th) * 0x10001u);
+        // per chain: low = 2*Th*cc - s, and the extremes of low / low + 2cc over the positions BEFORE each node
+        vr_s16x2 low = (vr_s16x2)(0), cc = (vr_s16x2)(0), amax = (vr_s16x2)(0), bmin = (vr_s16x2)(0);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            int lowv = 2 * Th * cc - s, upv = lowv + 2 * cc;   // at the position BEFORE node k
-            a = lowv > a ? lowv : a;
-            b = upv < b ? upv : b;
-            bool dec = pd[k] > 0 && (((forcedMask >> k) & 1u) || pd[k] > Th);
-            s += dec ? pd[k] : 0;
-            cc += dec ? 1 : 0;
+        for (int k = 0; k < 8; ++k) {
+            const vr_s16x2 dm = (__builtin_elementwise_min(Th2, h[k]) - pd[k]) >> 15;     // -1 where the node counts
+            low += pk_s(pk_u(dm) & pk_u(w2 - pd[k]));
+            cc -= dm;
+            if (k < 7) {
+                amax = __builtin_elementwise_max(amax, low);
+                bmin = __builtin_elementwise_min(bmin, low + cc + cc);
+            }
         }
-        uint32_t si = wave_incl_scan_u32((uint32_t)s, lane), ci2 = wave_incl_scan_u32((uint32_t)cc, lane);
-        int s0 = (int)(si - (uint32_t)s), c0 = (int)(ci2 - (uint32_t)cc);
+        const int low1 = low.x, low2 = low.y, cc1 = cc.x, cc2 = cc.y;
+        const int lowT = low1 + low2, ccT = cc1 + cc2;
+        int a = max((int)amax.x, max((int)amax.y, 0) + low1);          // chain 2 starts at position 8 (its own 0 included)
+        int b = min((int)bmin.x, min((int)bmin.y, 0) + low1 + 2 * cc1);
+        const uint32_t sT = (uint32_t)(2 * Th * ccT - lowT);
+        // one scan for both sums: s < 2^18 per wave, cc <= 1024
+        const uint32_t packed = sT | ((uint32_t)ccT << 20);
+        const uint32_t incl = wave_incl_scan_add_dpp(packed), excl = incl - packed;
+        const int s0 = (int)(excl & 0xFFFFFu), c0 = (int)(excl >> 20);
         a += 2 * Th * c0 - s0;
         b += 2 * (Th + 1) * c0 - s0;
-        for (int o = 32; o > 0; o >>= 1) {
-            int ua = __shfl_xor(a, o), ub = __shfl_xor(b, o);
-            a = ua > a ? ua : a;
-            b = ub < b ? ub : b;
-        }
-        uint32_t totS = __shfl(si, 63), totC = __shfl(ci2, 63);
-        if (lane == 0) { out->sumS[ci] = totS; out->sumC[ci] = totC; out->A[ci] = a; out->B[ci] = b; }
+        a = wave_max_i32_dpp(a);
+        b = -wave_max_i32_dpp(-b);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 0) { out->sumS[ci] = tot & 0xFFFFFu; out->sumC[ci] = tot >> 20; out->A[ci] = a; out->B[ci] = b; }
     }
 }
 
