@@ -821,7 +821,8 @@ k_prune_level(int d, const Ctrl *ctrls, uint8_t *__restrict__ codes, uint8_t *__
 __global__ void __launch_bounds__(256)
 k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
           uint8_t *__restrict__ codesRange, int64_t heapStride, int64_t codeStride, ReconBufs rb, int64_t leafStride,
-          int maxDepth, uint32_t *__restrict__ subTok, int64_t nEmitBlk, unsigned long long *__restrict__ blockL1)
+          int maxDepth, uint32_t *__restrict__ subTok, int64_t nEmitBlk, unsigned long long *__restrict__ blockL1,
+          int chainLo)
 {
     __shared__ uint8_t fl[2][2048];
     __shared__ uint16_t cnt[2][2048];      // tokens a (live) subtree emits, carried upwards with the flags
@@ -843,42 +844,85 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     const uint4 tv = *(const uint4 *)(temp + (int64_t)brick * heapStride + li);
     const uint4 rv = *(const uint4 *)(rb.b[c.par] + (int64_t)brick * leafStride + base + t * 16);
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
-    int maxErr = 0;
-    uint32_t pr = 0;            // pruned flags of my 16 leaves
-    uint8_t tl[16];             // tokens of my 16 leaves
-    int maxAfter = 0;
-    uint32_t l1After = 0;
+    // Sibling leaves 2j, 2j+1 share a packed 16-bit register pair.  State of a leaf: m = |truth - recon|,
+    // sg = 0xFFFF where truth < recon.  One step of the grown branch with distance d (encodeNode with the
+    // leaf's own reconstruction as parent, kd_common.h): x = min(d - m, sg ? t : 255 - t); taken iff |x| < m;
+    // then m = |x| and the side flips iff x > 0.
+    const uint32_t tol2 = (uint32_t)tol * 0x10001u;
+    uint32_t T2[8], m[8], sg[8], act[8], chain[8], nt[8];
+    uint32_t wa = 0, wb = 0, bothMask = 0, anyAct = 0;
+    vr_s16x2 mxB = (vr_s16x2)(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int sh = (k & 3) * 8;
-        const int code = (cpk >> (2 * k)) & 3, tt = (tw[k >> 2] >> sh) & 255, rec = (rw[k >> 2] >> sh) & 255;
-        const int err = rec > tt ? rec - tt : tt - rec;
-        maxErr = err > maxErr ? err : maxErr;
-        if (code == 0 && err < tol) {       // R.cpp:618-626
-            cpk |= 3u << (2 * k);
-            pr |= 1u << k;
-        } else if (code == 3) pr |= 1u << k;
-        // tokens this leaf emits when live: its code, then the grown branch (R.cpp:655-704)
-        int nt = 1, fe = err;
-        if (!((pr >> k) & 1u)) {            // an unpruned leaf is always live (pruning is closed downwards)
-            int r2 = rec, depth = D;
-            while (depth < maxDepth) {
-                const int e2 = r2 > tt ? r2 - tt : tt - r2;
-                if (e2 > tol) { ++depth; r2 = encode_node(tt, r2, 64 >> (depth - D - 1)).recon; ++nt; }
-                else { ++nt; break; }
-            }
-            fe = r2 > tt ? r2 - tt : tt - r2;
-        }
-        tl[k] = (uint8_t)nt;
-        maxAfter = fe > maxAfter ? fe : maxAfter;     // encoder's own statistics after branch growth,
-        l1After += (uint32_t)fe;                      // over every leaf (R.cpp:115-129)
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
+        T2[j] = __builtin_amdgcn_perm(0, tw[j >> 1], sel);
+        const vr_s16x2 dl = pk_s(T2[j]) - pk_s(__builtin_amdgcn_perm(0, rw[j >> 1], sel));
+        const vr_s16x2 mm = pk_abs(dl);
+        m[j] = pk_u(mm);
+        sg[j] = pk_u(dl >> 15);
+        mxB = __builtin_elementwise_max(mxB, mm);
+        const uint32_t lt = pk_u((mm - pk_s(tol2)) >> 15);                                     // err < tol
+        const uint32_t cl2 = ((cpk >> (4 * j)) & 3u) | (((cpk >> (4 * j + 2)) & 3u) << 16);     // the pair's codes
+        const uint32_t isz = pk_u((pk_s(cl2) - pk_s(0x00010001u)) >> 15), is3 = pk_u((pk_s(0x00020002u) - pk_s(cl2)) >> 15);
+        const uint32_t newp = isz & lt;                                                        // R.cpp:618-626
+        const uint32_t pruned = newp | is3;
+        if (j < 4) wa |= (newp & 0x000C0003u) << (4 * j); else wb |= (newp & 0x000C0003u) << (4 * (j - 4));
+        bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
+        act[j] = ~pruned;                 // an unpruned leaf is always live (pruning is closed downwards)
+        anyAct |= act[j];
+        chain[j] = 0;
+        nt[j] = 0x00010001u;              // tokens the leaf emits when live: its code, then the grown branch
     }
+    cpk |= ((wa | (wa >> 16)) & 0xFFFFu) | ((wb | (wb >> 16)) << 16);
+    const int nsteps = maxDepth - D;      // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
+    for (int i = 0; i < nsteps; ++i) {
+        if (__ballot(anyAct != 0) == 0ull) break;        // wave-uniform: every branch of the wave has ended
+        const uint32_t d2 = (uint32_t)(64 >> i) * 0x10001u;
+        anyAct = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const vr_s16x2 mm = pk_s(m[j]);
+            const uint32_t gt = pk_u((pk_s(tol2) - mm) >> 15);                                 // err > tol: grow
+            nt[j] = pk_u(pk_s(nt[j]) - pk_s(act[j]));                                          // a code or the terminator
+            const uint32_t go = act[j] & gt;
+            const uint32_t term = (act[j] ^ go) & 0x00030003u;                                 // R.cpp:699-703
+            const uint32_t lim = (sg[j] & T2[j]) | (~sg[j] & (T2[j] ^ 0x00FF00FFu));
+            const vr_s16x2 x = __builtin_elementwise_min(pk_s(d2) - mm, pk_s(lim));
+            const vr_s16x2 nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
+            const uint32_t take = go & pk_u((ax - mm) >> 15);
+            const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[j]));                        // add = 1, sub = 2
+            chain[j] |= ((take & dir) | term) << (2 * i);
+            m[j] = (take & pk_u(ax)) | (~take & m[j]);
+            sg[j] ^= take & pk_u(nx >> 15);
+            act[j] = go;
+            anyAct |= go;
+        }
+    }
+    vr_s16x2 mxA = (vr_s16x2)(0), l1p = (vr_s16x2)(0);   // encoder's own statistics after branch growth,
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                         // over every leaf (R.cpp:115-129)
+        mxA = __builtin_elementwise_max(mxA, pk_s(m[j]));
+        l1p += pk_s(m[j]);
+    }
+    int maxErr = max((int)mxB.x, (int)mxB.y), maxAfter = max((int)mxA.x, (int)mxA.y);
+    const uint32_t l1After = (uint32_t)((int)l1p.x + (int)l1p.y);
+    uint32_t pr = 0;            // pruned flags of sibling pairs: bit k <=> both leaves 2k, 2k+1 pruned
+    pr = bothMask;
     *(uint32_t *)(Cb + (li >> 2)) = cpk;
     if (CR) {
         uint32_t q = *(const uint32_t *)(CR + (li >> 2));
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if ((pr >> k) & 1u) q |= 3u << (2 * k);   // M.cpp:864-865
+        q |= (cpk & (cpk >> 1) & 0x55555555u) * 3u;     // every pruned leaf: range code 3 as well (M.cpp:864-865)
         *(uint32_t *)(CR + (li >> 2)) = q;
+    }
+    if (chainLo) {              // the grown branches, for k_emit4: 14 bits per leaf as two byte planes
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lo[q] = __builtin_amdgcn_perm(chain[2 * q + 1], chain[2 * q], 0x06040200u);
+            hi[q] = __builtin_amdgcn_perm(chain[2 * q + 1], chain[2 * q], 0x07050301u);
+        }
+        *(uint4 *)(rb.b[c.ra] + (int64_t)brick * leafStride + base + t * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *(uint4 *)(rb.b[c.rb] + (int64_t)brick * leafStride + base + t * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     }
     unsigned long long l1w = l1After;
     for (int o = 32; o > 0; o >>= 1) {
@@ -897,13 +941,13 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         uint32_t v = *(const uint16_t *)(Cb + (ni >> 2)), vr = CR ? *(const uint16_t *)(CR + (ni >> 2)) : 0u;   // 8 codes
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const bool both = ((pr >> (2 * k)) & 3u) == 3u;
+            const bool both = (pr >> k) & 1u;
             const int code = (int)((v >> (2 * k)) & 3u);
             const bool p = both && code == 0;
             if (p) { v |= 3u << (2 * k); vr |= 3u << (2 * k); }
             const bool f3 = p || code == 3;
             fl[1][t * 8 + k] = (uint8_t)(f3 ? 1 : 0);
-            cnt[1][t * 8 + k] = (uint16_t)(f3 ? 1 : 1 + tl[2 * k] + tl[2 * k + 1]);
+            cnt[1][t * 8 + k] = (uint16_t)(f3 ? 1u : 1u + (nt[k] & 0xFFFFu) + (nt[k] >> 16));
         }
         *(uint16_t *)(Cb + (ni >> 2)) = (uint16_t)v;
         if (CR) *(uint16_t *)(CR + (ni >> 2)) = (uint16_t)vr;
@@ -1219,15 +1263,16 @@ __device__ __forceinline__ void str_put(Str128 &s, uint32_t bits, int ntok)
     s.n += ntok;
 }
 
-struct Quad { Str128 s; int preDs, aliveAtDs, maxErr; uint32_t l1; };
+struct Quad { Str128 s; int preDs, aliveAtDs; };
 
 // inner: codes of the block's internal nodes at depths D-10 .. D-3, heap-ordered (node (l, i) at (1<<l)+i)
-__device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ Tb,
-                                   const uint8_t *__restrict__ Rl, const uint8_t *inner, bool rootLive,
-                                   unsigned long long upSpine, int D, int maxDepth, int tol, int Ds, uint32_t r0)
+// chLo/chHi: the leaves' grown branches as k_prune12 left them (14 bits per leaf, two byte planes)
+__device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ chLo,
+                                   const uint8_t *__restrict__ chHi, const uint8_t *inner, bool rootLive,
+                                   unsigned long long upSpine, int D, int maxDepth, int Ds, uint32_t r0)
 {
     Quad Q;
-    Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0; Q.maxErr = 0; Q.l1 = 0;
+    Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0;
     const uint32_t lr = r0 & 1023u;                                  // rank inside the block
     // every global load is issued before any is looked at: one memory latency, no dependent chain
     const int quadCode = cget(Cb, ((int64_t)1 << (D - 2)) + (r0 >> 2));
@@ -1236,8 +1281,9 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
     const uint32_t pair = (pk2 & 3u) | ((pk2 >> 2) << 8);
     const uint32_t clb = Cb[(((int64_t)1 << D) + r0) >> 2];                          // my four leaf codes = one byte
     const uint32_t cl = (clb & 3u) | (((clb >> 2) & 3u) << 8) | (((clb >> 4) & 3u) << 16) | (((clb >> 6) & 3u) << 24);
-    const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
-    const uint32_t rl = *(const uint32_t *)(Rl + r0);
+    const uint32_t hl = *(const uint32_t *)(chLo + r0);
+    const uint32_t hh = *(const uint32_t *)(chHi + r0);
+    const int nsteps = maxDepth - D;
     bool alive;
     int j;
     if (lr == 0) {                            // first rank of the block: the spine above depth D-10 comes precomputed
@@ -1269,29 +1315,16 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
         for (int e = 0; e < 2; ++e) {
             const int k = 2 * h + e;
             if (k == 0 && D == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
-            const int code = (cl >> (8 * k)) & 255, t = (tl >> (8 * k)) & 255;
-            int rec = (rl >> (8 * k)) & 255;
-            uint32_t bits = (uint32_t)code;
+            const uint32_t code = (cl >> (8 * k)) & 255u;
+            uint32_t bits = code;
             int nt = 1;
-            if (code != 3) {
-                int depth = D;
-                while (depth < maxDepth) {                          // grown branch, R.cpp:655-704
-                    const int err = rec > t ? rec - t : t - rec;
-                    if (err > tol) {
-                        ++depth;
-                        // distanceMap[D+1..D+7] is 64,32,..,1 by construction (R.cpp:23,94-97): no memory load
-                        // inside this dependent loop
-                        const Enc en = encode_node(t, rec, 64 >> (depth - D - 1));
-                        rec = en.recon;
-                        bits |= (uint32_t)en.code << (2 * nt);
-                        ++nt;
-                    } else { bits |= 3u << (2 * nt); ++nt; break; }
-                }
+            if (code != 3) {                                         // grown branch, R.cpp:655-704
+                const uint32_t ch = ((hl >> (8 * k)) & 255u) | (((hh >> (8 * k)) & 255u) << 8);
+                const uint32_t t3 = ch & (ch >> 1) & 0x1555u;        // the terminator, if the branch has one
+                nt += t3 ? ((__ffs((int)t3) - 1) >> 1) + 1 : nsteps;
+                bits |= ch << 2;
             }
             str_put(Q.s, bits, nt);
-            const int fe = rec > t ? rec - t : t - rec;
-            Q.maxErr = fe > Q.maxErr ? fe : Q.maxErr;
-            Q.l1 += (uint32_t)fe;
         }
     }
     return Q;
@@ -1346,8 +1379,8 @@ k_emit4(EmitArgs a)
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
-    const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
-    const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
+    const uint8_t *chLo = a.rb.b[c.ra] + (int64_t)brick * a.leafStride;   // k_prune12's branch records live in the two
+    const uint8_t *chHi = a.rb.b[c.rb] + (int64_t)brick * a.leafStride;   // reconstruction buffers the level loop left free
     const uint32_t r0 = blockIdx.x * EMIT4_RANKS + threadIdx.x * 4;
     __shared__ uint8_t inner[256];
     const int64_t bo = (int64_t)brick * a.nEmitBlk + blockIdx.x;
@@ -1370,7 +1403,7 @@ k_emit4(EmitArgs a)
     }
     if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
     __syncthreads();
-    const Quad Q = quad_tokens(Cb, Tb, Rl, inner, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.tol, a.Ds, r0);
+    const Quad Q = quad_tokens(Cb, chLo, chHi, inner, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.Ds, r0);
     uint32_t tot;
     const uint32_t lo = block_excl_scan_u32((uint32_t)Q.s.n, shw, tot);
     if (!WRITE) {
@@ -1604,7 +1637,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
                            bs->codeStride, rb, bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
                            bs->nEmitBlk,    // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
-                           (!mr && bs->K >= 2) ? bs->blockL1 : nullptr);
+                           (!mr && bs->K >= 2) ? bs->blockL1 : nullptr, (!mr && bs->K >= 2) ? 1 : 0);
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
