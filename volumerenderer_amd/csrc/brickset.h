@@ -43,6 +43,7 @@ struct BrickSet {
     uint8_t *idxValCut = nullptr; // B * nIdx  progressive cut above the index level: ancestor scalars
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
+    uint32_t *spread = nullptr;  // rank bits of every x, y, z coordinate: rank(x,y,z) = spread[x] | spread[X+y] | spread[X+Y+z]
 
     std::vector<Ctrl> hostCtrl; // copied back lazily
     bool built = false, hostCtrlValid = false;

@@ -161,7 +161,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_stream2(b.rng);
     for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
     hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine);
-    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.lut);
+    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.lut); hipFree(b.spread);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;
     return VR_OK;
@@ -205,6 +205,23 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
             std::vector<uint32_t> lut;
             make_lut(b.g, b.K, lut);
             e = hipMemcpy(b.lut, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) e = hipMalloc(&b.spread, (size_t)(b.g.X + b.g.Y + b.g.Z) * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            // kernels never walk Geom::axis/bit (a dependent chain of loads from the kernel-argument
+            // segment): a coordinate's contribution to the Morton rank comes from this table
+            std::vector<uint32_t> sp((size_t)(b.g.X + b.g.Y + b.g.Z), 0u);
+            const int off[3] = {0, b.g.X, b.g.X + b.g.Y}, ext[3] = {b.g.X, b.g.Y, b.g.Z};
+            for (int ax = 0; ax < 3; ++ax)
+                for (int v = 0; v < ext[ax]; ++v) {
+                    uint32_t r = 0;
+                    for (int d = 0; d < b.g.D; ++d) {
+                        r <<= 1;
+                        if (b.g.axis[d] == ax) r |= (uint32_t)(v >> b.g.bit[d]) & 1u;
+                    }
+                    sp[(size_t)off[ax] + v] = r;
+                }
+            e = hipMemcpy(b.spread, sp.data(), sp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
         for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&b.ev[i]);
         if (e != hipSuccess) rc = e == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_NO_DEVICE;

@@ -121,6 +121,35 @@ __device__ __forceinline__ vr_s16x2 enc_pair_err(const EncPair &c, uint32_t d2)
 {
     return __builtin_elementwise_min(c.pd, pk_abs(enc_pair_x(c, d2)));
 }
+// wave64 inclusive scans on the DPP network (row shifts inside 16-lane rows, then the two row
+// broadcasts): six VALU instructions instead of six LDS-crossbar shuffles.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_add_dpp(uint32_t v)
+{
+    v += dpp_u32<0x111, 0xf>(0, v);   // row_shr:1
+    v += dpp_u32<0x112, 0xf>(0, v);   // row_shr:2
+    v += dpp_u32<0x114, 0xf>(0, v);   // row_shr:4
+    v += dpp_u32<0x118, 0xf>(0, v);   // row_shr:8
+    v += dpp_u32<0x142, 0xa>(0, v);   // row_bcast:15 into rows 1, 3
+    v += dpp_u32<0x143, 0xc>(0, v);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32_dpp(int v)   // result valid in lane 63 (returned via readlane)
+{
+    const uint32_t I = 0x80000000u;
+    v = max(v, (int)dpp_u32<0x111, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x112, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x114, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x118, 0xf>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x142, 0xa>(I, (uint32_t)v));
+    v = max(v, (int)dpp_u32<0x143, 0xc>(I, (uint32_t)v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 #endif
 
 // decoder step (R.cpp:783-787): child scalar from parent scalar and the child's code

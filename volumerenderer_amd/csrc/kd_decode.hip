@@ -154,6 +154,7 @@ struct TileArgs {
     int tilesX, tilesY, tilesZ;
     int cut;                    // progressive cut depth (maxTreeDepth = the reference's levelCut)
     const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
+    const uint32_t *spread;     // BrickSet::spread (coordinate -> Morton rank bits)
 };
 
 #define DEC_WAVES 4
@@ -242,9 +243,8 @@ k_decode_tile(TileArgs a)
     const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
 
     // ---- which subtree is mine
-    int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};   // subtree coords (units of 4 voxels)
-    uint32_t s = 0;
-    for (int d = 0; d < a.Ds; ++d) s = (s << 1) | ((uint32_t)(sc[a.g.axis[d]] >> (a.g.bit[d] - 2)) & 1u);
+    const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};   // subtree coords (units of 4 voxels)
+    const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
     const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
     const int val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
 
@@ -402,7 +402,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
         t.tree = bs->mid.tree; t.treeCap = bs->treeCap;
         t.idxOff = bs->idxOff; t.idxVal = bs->idxVal; t.nIdx = bs->nIdx;
         t.ctrls = bs->mid.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
-        t.cut = cut; t.idxValCut = cutVals;
+        t.cut = cut; t.idxValCut = cutVals; t.spread = bs->spread;
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
         hipLaunchKernelGGL(k_decode_tile, dim3((unsigned)((ntiles + DEC_WAVES - 1) / DEC_WAVES), bs->B),
                            dim3(64 * DEC_WAVES), 0, st, t);

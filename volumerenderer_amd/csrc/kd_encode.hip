@@ -88,74 +88,139 @@ k_pyramid(Geom g, int dLeaf, int L, const uint8_t *__restrict__ vox, const uint8
 // 16-byte x-run of voxels (coalesced), scatters it to Morton order in LDS, and the block
 // reduces min/max twelve times there; leaves and the dense levels leave as 16/8/4-byte
 // stores.  Replaces the per-voxel gather of k_pyramid<true>.
-struct Pyr12Geom { int ax, ay, az; uint16_t sx[16]; };   // sx[i]: Morton rank bits of x = i (low 4 x bits)
+struct Pyr12Geom {
+    int ax, ay, az; uint16_t sx[16];   // sx[i]: Morton rank bits of x = i (low 4 x bits)
+    // XCD-aware block order (swz != 0): the eight 16-voxel-wide boxes that share every 128-byte line of an
+    // x-run go to the same XCD (workgroup id mod 8) back to back, so that XCD's L2 fetches each line once
+    int swz, nbx, nby;
+    const uint32_t *spread;            // BrickSet::spread
+};
+
+// (min,max) of sibling pairs held in packed 16-bit lanes: A = (a0,a1), B = (b0,b1) -> (f(a0,a1), f(b0,b1))
+__device__ __forceinline__ vr_s16x2 pk_pair_min(uint32_t A, uint32_t B)
+{
+    return __builtin_elementwise_min(pk_s(__builtin_amdgcn_perm(B, A, 0x05040100u)), pk_s(__builtin_amdgcn_perm(B, A, 0x07060302u)));
+}
+__device__ __forceinline__ vr_s16x2 pk_pair_max(uint32_t A, uint32_t B)
+{
+    return __builtin_elementwise_max(pk_s(__builtin_amdgcn_perm(B, A, 0x05040100u)), pk_s(__builtin_amdgcn_perm(B, A, 0x07060302u)));
+}
+__device__ __forceinline__ uint32_t pk_mid(vr_s16x2 mn, vr_s16x2 mx) { return pk_u((mn + mx) >> 1); }   // R.cpp:198
+__device__ __forceinline__ uint32_t pk_half_range(vr_s16x2 mn, vr_s16x2 mx) { return pk_u((mx - mn) >> 1); } // M.cpp:235
 
 __global__ void __launch_bounds__(256)
 k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__restrict__ temp, int64_t heapStride,
             uint8_t *__restrict__ tempRange, uint8_t *__restrict__ outMin, uint8_t *__restrict__ outMax,
             int64_t outStride)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smn[2][4096], smx[2][4096];
+    __shared__ __attribute__((aligned(16))) uint8_t leaf[4096];
+    __shared__ uint32_t waveMM[4];
     const int brick = blockIdx.y, D = g.D;
-    const uint32_t base = blockIdx.x << 12;
+    // which 2^ax x 2^ay x 2^az box: enumerated by box coordinates (x fastest), not by Morton index
+    uint32_t bid = blockIdx.x;
+    if (pg.swz) {
+        const uint32_t slot = bid >> 3;
+        const uint32_t grp = (slot >> 3) * 8u + (bid & 7u), m = slot & 7u;       // group -> XCD grp % 8, members in a row
+        const uint32_t ngx = (uint32_t)pg.nbx >> 3;
+        bid = (grp / ngx) * (uint32_t)pg.nbx + (grp % ngx) * 8u + m;
+    }
+    const int bx = (int)((bid % (uint32_t)pg.nbx) << pg.ax), by = (int)(((bid / (uint32_t)pg.nbx) % (uint32_t)pg.nby) << pg.ay),
+              bz = (int)((bid / ((uint32_t)pg.nbx * (uint32_t)pg.nby)) << pg.az);
+    const uint32_t *sp = pg.spread;
+    const uint32_t base = sp[bx] | sp[g.X + by] | sp[g.X + g.Y + bz];           // Morton rank of the box origin
     uint8_t *T = temp + (int64_t)brick * heapStride;
     uint8_t *TR = tempRange ? tempRange + (int64_t)brick * heapStride : nullptr;
-    int bx, by, bz;
-    rank_to_xyz(g, base, bx, by, bz);
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
     const int nxs = 1 << (pg.ax - 4);
     const int xs = t & (nxs - 1), y = (t >> (pg.ax - 4)) & ((1 << pg.ay) - 1), z = t >> (pg.ax - 4 + pg.ay);
-    // Morton rank of (xs*16, y, z) inside the box: walk the 12 deepest split levels
-    uint32_t r0 = 0;
-    {
-        const int cx = xs * 16, c[3] = {cx, y, z};
-        for (int q = 0; q < 12; ++q) {
-            const int dd = D - 12 + q;
-            r0 = (r0 << 1) | ((uint32_t)(c[g.axis[dd]] >> g.bit[dd]) & 1u);
-        }
-    }
+    // Morton rank of (xs*16, y, z) inside the box (the 12 deepest split levels)
+    const uint32_t r0 = sp[xs * 16] | sp[g.X + y] | sp[g.X + g.Y + z];
     const uint4 v4 = *(const uint4 *)(vox + (int64_t)brick * g.voxels + (bx + xs * 16) +
                                       (int64_t)g.X * ((by + y) + (int64_t)g.Y * (bz + z)));
     const uint32_t vw[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint8_t v = (uint8_t)(vw[i >> 2] >> ((i & 3) * 8));
-        const uint32_t r = r0 | pg.sx[i];
-        smn[0][r] = v;
-        smx[0][r] = v;
-    }
+    for (int i = 0; i < 16; ++i) leaf[r0 | pg.sx[i]] = (uint8_t)(vw[i >> 2] >> ((i & 3) * 8));
     __syncthreads();
-    // leaves: 16 per thread, Morton order is the heap's leaf order
-    *(uint4 *)(T + ((int64_t)1 << D) + base + t * 16) = *(const uint4 *)(&smn[0][t * 16]);   // (v+v)/2 = v
+    // 16 Morton-consecutive leaves per thread: they and the four levels above them never leave registers
+    const uint4 lv = *(const uint4 *)(&leaf[t * 16]);
+    *(uint4 *)(T + ((int64_t)1 << D) + base + t * 16) = lv;                         // leaf: (v+v)/2 = v
     if (TR) *(uint4 *)(TR + ((int64_t)1 << D) + base + t * 16) = make_uint4(0, 0, 0, 0);
-    for (int l = 1; l <= 12; ++l) {
-        const int m = 4096 >> l;
-        const int src = (l - 1) & 1, dst = l & 1;
-        const int npt = m >= 256 ? m / 256 : 1;        // 8, 4, 2, 1, 1, ...
-        const int64_t lvl = ((int64_t)1 << (D - l)) + (base >> l);
-        if (t * npt < m) {
-            unsigned long long packM = 0, packR = 0;
-            for (int k = 0; k < npt; ++k) {
-                const int i = t * npt + k;
-                const uint8_t a = smn[src][2 * i], b = smn[src][2 * i + 1];
-                const uint8_t c = smx[src][2 * i], d2 = smx[src][2 * i + 1];
-                const uint8_t mn = a < b ? a : b, mx = c > d2 ? c : d2;
-                smn[dst][i] = mn;
-                smx[dst][i] = mx;
-                packM |= (unsigned long long)(((int)mx + (int)mn) >> 1) << (8 * k);   // R.cpp:198
-                packR |= (unsigned long long)(((int)mx - (int)mn) >> 1) << (8 * k);   // M.cpp:235
-            }
-            uint8_t *dstp = T + lvl + t * npt;
-            if (npt == 8) { *(unsigned long long *)dstp = packM; if (TR) *(unsigned long long *)(TR + lvl + t * 8) = packR; }
-            else if (npt == 4) { *(uint32_t *)dstp = (uint32_t)packM; if (TR) *(uint32_t *)(TR + lvl + t * 4) = (uint32_t)packR; }
-            else if (npt == 2) { *(uint16_t *)dstp = (uint16_t)packM; if (TR) *(uint16_t *)(TR + lvl + t * 2) = (uint16_t)packR; }
-            else { *dstp = (uint8_t)packM; if (TR) TR[lvl + t] = (uint8_t)packR; }
-        }
-        __syncthreads();
+    const uint32_t w[4] = {lv.x, lv.y, lv.z, lv.w};
+    vr_s16x2 mn1[4], mx1[4];
+    uint32_t md[4], hr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // level D-1: lanes = nodes 2q, 2q+1
+        const vr_s16x2 lo = pk_s(w[q] & 0x00FF00FFu), hi = pk_s((w[q] >> 8) & 0x00FF00FFu);
+        mn1[q] = __builtin_elementwise_min(lo, hi);
+        mx1[q] = __builtin_elementwise_max(lo, hi);
+        md[q] = pk_mid(mn1[q], mx1[q]);
+        hr[q] = pk_half_range(mn1[q], mx1[q]);
     }
-    if (t == 0) {
-        outMin[(int64_t)brick * outStride + blockIdx.x] = smn[0][0];
-        outMax[(int64_t)brick * outStride + blockIdx.x] = smx[0][0];
+    {
+        const int64_t o = ((int64_t)1 << (D - 1)) + (base >> 1) + t * 8;
+        *(uint2 *)(T + o) = make_uint2(__builtin_amdgcn_perm(md[1], md[0], 0x06040200u), __builtin_amdgcn_perm(md[3], md[2], 0x06040200u));
+        if (TR) *(uint2 *)(TR + o) = make_uint2(__builtin_amdgcn_perm(hr[1], hr[0], 0x06040200u), __builtin_amdgcn_perm(hr[3], hr[2], 0x06040200u));
+    }
+    vr_s16x2 mn2[2], mx2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                       // level D-2
+        mn2[q] = pk_pair_min(pk_u(mn1[2 * q]), pk_u(mn1[2 * q + 1]));
+        mx2[q] = pk_pair_max(pk_u(mx1[2 * q]), pk_u(mx1[2 * q + 1]));
+    }
+    {
+        const int64_t o = ((int64_t)1 << (D - 2)) + (base >> 2) + t * 4;
+        *(uint32_t *)(T + o) = __builtin_amdgcn_perm(pk_mid(mn2[1], mx2[1]), pk_mid(mn2[0], mx2[0]), 0x06040200u);
+        if (TR) *(uint32_t *)(TR + o) = __builtin_amdgcn_perm(pk_half_range(mn2[1], mx2[1]), pk_half_range(mn2[0], mx2[0]), 0x06040200u);
+    }
+    const vr_s16x2 mn3 = pk_pair_min(pk_u(mn2[0]), pk_u(mn2[1])), mx3 = pk_pair_max(pk_u(mx2[0]), pk_u(mx2[1]));   // level D-3
+    {
+        const int64_t o = ((int64_t)1 << (D - 3)) + (base >> 3) + t * 2;
+        const uint32_t m3 = pk_mid(mn3, mx3), h3 = pk_half_range(mn3, mx3);
+        *(uint16_t *)(T + o) = (uint16_t)((m3 & 0xFFu) | ((m3 >> 8) & 0xFF00u));
+        if (TR) *(uint16_t *)(TR + o) = (uint16_t)((h3 & 0xFFu) | ((h3 >> 8) & 0xFF00u));
+    }
+    int mn = min((int)mn3.x, (int)mn3.y), mx = max((int)mx3.x, (int)mx3.y);        // level D-4: one node per thread
+    {
+        const int64_t o = ((int64_t)1 << (D - 4)) + (base >> 4) + t;
+        T[o] = (uint8_t)((mn + mx) >> 1);
+        if (TR) TR[o] = (uint8_t)((mx - mn) >> 1);
+    }
+    // levels D-5 .. D-10 inside the wave: (min, 255 - max) packed so that one packed min reduces both
+    uint32_t p = (uint32_t)mn | ((uint32_t)(255 - mx) << 16);
+#pragma unroll
+    for (int k = 1; k <= 6; ++k) {
+        uint32_t q;
+        if (k == 1) q = dpp_u32<0x101, 0xf>(p, p);          // row_shl:1 (lane i <- lane i+1)
+        else if (k == 2) q = dpp_u32<0x102, 0xf>(p, p);
+        else if (k == 3) q = dpp_u32<0x104, 0xf>(p, p);
+        else if (k == 4) q = dpp_u32<0x108, 0xf>(p, p);
+        else q = (uint32_t)__shfl_down((int)p, 1 << (k - 1));
+        p = pk_u(__builtin_elementwise_min(pk_s(p), pk_s(q)));
+        if ((lane & ((1 << k) - 1)) == 0) {
+            const int a = (int)(p & 0xFFFFu), b = 255 - (int)(p >> 16);
+            const int64_t o = ((int64_t)1 << (D - 4 - k)) + (base >> (4 + k)) + (t >> k);
+            T[o] = (uint8_t)((a + b) >> 1);
+            if (TR) TR[o] = (uint8_t)((b - a) >> 1);
+        }
+    }
+    if (lane == 0) waveMM[t >> 6] = p;
+    __syncthreads();
+    if (t == 0) {                                       // levels D-11 (two nodes) and D-12 (the block's root)
+        int a[2], b[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t u = pk_u(__builtin_elementwise_min(pk_s(waveMM[2 * h]), pk_s(waveMM[2 * h + 1])));
+            a[h] = (int)(u & 0xFFFFu); b[h] = 255 - (int)(u >> 16);
+            const int64_t o = ((int64_t)1 << (D - 11)) + (base >> 11) + h;
+            T[o] = (uint8_t)((a[h] + b[h]) >> 1);
+            if (TR) TR[o] = (uint8_t)((b[h] - a[h]) >> 1);
+        }
+        const int ra = min(a[0], a[1]), rbm = max(b[0], b[1]);
+        const int64_t o = ((int64_t)1 << (D - 12)) + (base >> 12);
+        T[o] = (uint8_t)((ra + rbm) >> 1);
+        if (TR) TR[o] = (uint8_t)((rbm - ra) >> 1);
+        outMin[(int64_t)brick * outStride + (base >> 12)] = (uint8_t)ra;
+        outMax[(int64_t)brick * outStride + (base >> 12)] = (uint8_t)rbm;
     }
 }
 
@@ -298,35 +363,6 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
             c.estTbase = est_window_base((long long)(S / (2ull * C + 1ull)), 4);
         }
     }
-}
-
-// wave64 inclusive scans on the DPP network (row shifts inside 16-lane rows, then the two row
-// broadcasts): six VALU instructions instead of six LDS-crossbar shuffles.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_add_dpp(uint32_t v)
-{
-    v += dpp_u32<0x111, 0xf>(0, v);   // row_shr:1
-    v += dpp_u32<0x112, 0xf>(0, v);   // row_shr:2
-    v += dpp_u32<0x114, 0xf>(0, v);   // row_shr:4
-    v += dpp_u32<0x118, 0xf>(0, v);   // row_shr:8
-    v += dpp_u32<0x142, 0xa>(0, v);   // row_bcast:15 into rows 1, 3
-    v += dpp_u32<0x143, 0xc>(0, v);   // row_bcast:31 into rows 2, 3
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32_dpp(int v)   // result valid in lane 63 (returned via readlane)
-{
-    const uint32_t I = 0x80000000u;
-    v = max(v, (int)dpp_u32<0x111, 0xf>(I, (uint32_t)v));
-    v = max(v, (int)dpp_u32<0x112, 0xf>(I, (uint32_t)v));
-    v = max(v, (int)dpp_u32<0x114, 0xf>(I, (uint32_t)v));
-    v = max(v, (int)dpp_u32<0x118, 0xf>(I, (uint32_t)v));
-    v = max(v, (int)dpp_u32<0x142, 0xa>(I, (uint32_t)v));
-    v = max(v, (int)dpp_u32<0x143, 0xc>(I, (uint32_t)v));
-    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // One wave per segment, 16 consecutive nodes per lane as two chains of 8 (nodes k and k+8 share a
@@ -1592,6 +1628,11 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
             }
         }
         if (use12) {
+            const int64_t Bx = bs->g.X >> pg.ax, By = bs->g.Y >> pg.ay, Bz = bs->g.Z >> pg.az;
+            const int64_t perLine = (bs->g.X < 128 ? bs->g.X : 128) >> pg.ax;
+            pg.swz = (perLine == 8 && Bx % 8 == 0 && ((Bx / 8) * By * Bz) % 8 == 0 && !getenv("VRHIP_NOSWZ")) ? 1 : 0;
+            pg.nbx = (int)Bx; pg.nby = (int)By;
+            pg.spread = bs->spread;
             hipLaunchKernelGGL(k_pyramid12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, bs->g, pg, vox,
                                bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr, bs->mmMin[0], bs->mmMax[0],
                                oStride);
