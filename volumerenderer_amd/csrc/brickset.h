@@ -36,6 +36,7 @@ struct BrickSet {
     unsigned long long *blockL1 = nullptr; // B * nEmitBlk
     uint8_t *blockAlive = nullptr, *blockVal = nullptr;   // B * nEmitBlk
     unsigned long long *blockSpine = nullptr; // B * nEmitBlk
+    uint32_t *chainLut = nullptr;   // 256: grown branch of a leaf by its initial error (k_chain_lut)
     uint32_t *blockTot = nullptr, *blockOff = nullptr; // B * nEmitBlk
     int64_t nEmitBlk = 0;
     uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)

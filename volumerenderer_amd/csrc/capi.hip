@@ -148,6 +148,7 @@ static vr_status ensure_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.blockAlive, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockVal, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockSpine, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b.chainLut, 256 * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     return VR_OK;
@@ -160,7 +161,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_stream2(b.mid);
     free_stream2(b.rng);
     for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
-    hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine);
+    hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine); hipFree(b.chainLut);
     hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.lut); hipFree(b.spread);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;

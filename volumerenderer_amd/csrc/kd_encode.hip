@@ -849,6 +849,28 @@ k_prune_level(int d, const Ctrl *ctrls, uint8_t *__restrict__ codes, uint8_t *__
     }
 }
 
+// The grown branch of a leaf (R.cpp:655-704: encodeNode against the leaf's own reconstruction with
+// distances 64, 32, .., 1 until the error is within tolerance) depends only on the initial error
+// m0 = |truth - recon| and the side, as long as the clamps at 0 / 255 cannot matter: a clamped step
+// lands min(truth, 255 - truth) away from the truth, which is never an improvement while that is
+// >= the current error.  lut[m0] = tokens (2 bits each, "add" = towards the truth first) | count << 14
+// | final error << 20; the other side swaps add <-> sub.  Leaves with m0 > min(t, 255 - t) take
+// the exact step-by-step path.
+__global__ void k_chain_lut(int tol, int nsteps, uint32_t *__restrict__ lut)
+{
+    const int m0 = threadIdx.x, t = 128;
+    int rec = m0 <= 127 ? t - m0 : 0;
+    uint32_t bits = 0, n = 0;
+    for (int i = 0; i < nsteps; ++i) {
+        const int err = rec > t ? rec - t : t - rec;
+        if (err > tol) { const Enc e = encode_node(t, rec, 64 >> i); rec = e.recon; bits |= (uint32_t)e.code << (2 * n); ++n; }
+        else { bits |= 3u << (2 * n); ++n; break; }
+    }
+    const int fe = rec > t ? rec - t : t - rec;
+    lut[m0] = bits | (n << 14) | ((uint32_t)fe << 20);
+}
+__device__ __forceinline__ uint32_t chain_mirror(uint32_t ch) { return ch ^ (((ch ^ (ch >> 1)) & 0x1555u) * 3u); }   // add <-> sub
+
 // Leaf prune + the 12 levels above it in one block (the level-synchronous kernels above
 // stay for small bricks and for the levels nearer the root): 16 leaves per thread as
 // 16-byte loads, pruned flags carried upwards in LDS, each level's codes read-modified-
@@ -858,8 +880,9 @@ __global__ void __launch_bounds__(256)
 k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
           uint8_t *__restrict__ codesRange, int64_t heapStride, int64_t codeStride, ReconBufs rb, int64_t leafStride,
           int maxDepth, uint32_t *__restrict__ subTok, int64_t nEmitBlk, unsigned long long *__restrict__ blockL1,
-          int chainLo)
+          const uint32_t *__restrict__ chainLut)
 {
+    __shared__ uint32_t lutS[256];
     __shared__ uint8_t fl[2][2048];
     __shared__ uint16_t cnt[2][2048];      // tokens a (live) subtree emits, carried upwards with the flags
     __shared__ uint8_t lv[2048], lvOld[2048];     // codes of the block's nodes at depths D-12 .. D-2, heap order
@@ -869,6 +892,7 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     const uint32_t base = blockIdx.x << 12;
     uint8_t *Cb = codes + (int64_t)brick * codeStride;
     uint8_t *CR = codesRange ? codesRange + (int64_t)brick * codeStride : nullptr;
+    lutS[t] = chainLut[t];
     for (int h = 1 + t; h < 2048; h += 256) {
         const int lq = 31 - __clz(h);
         const uint8_t cv0 = (uint8_t)cget(Cb, ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq)));
@@ -885,9 +909,10 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     // leaf's own reconstruction as parent, kd_common.h): x = min(d - m, sg ? t : 255 - t); taken iff |x| < m;
     // then m = |x| and the side flips iff x > 0.
     const uint32_t tol2 = (uint32_t)tol * 0x10001u;
-    uint32_t T2[8], m[8], sg[8], act[8], chain[8], nt[8];
+    uint32_t T2[8], m[8], sg[8], act[8], nt[8];
     uint32_t wa = 0, wb = 0, bothMask = 0, anyAct = 0;
     vr_s16x2 mxB = (vr_s16x2)(0);
+    __syncthreads();                      // lutS
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
@@ -904,10 +929,16 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         const uint32_t pruned = newp | is3;
         if (j < 4) wa |= (newp & 0x000C0003u) << (4 * j); else wb |= (newp & 0x000C0003u) << (4 * (j - 4));
         bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
-        act[j] = ~pruned;                 // an unpruned leaf is always live (pruning is closed downwards)
+        // an unpruned leaf is always live (pruning is closed downwards): its code, then the grown branch --
+        // from the table unless a clamp could matter (m > min(t, 255 - t)), then step by step below
+        const vr_s16x2 lim = __builtin_elementwise_min(pk_s(T2[j]), pk_s(T2[j] ^ 0x00FF00FFu));
+        const uint32_t viol = pk_u((lim - mm) >> 15);
+        const uint32_t e0 = lutS[m[j] & 255u], e1 = lutS[(m[j] >> 16) & 255u];
+        const uint32_t useL = ~pruned & ~viol;
+        nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
+        m[j] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[j]);
+        act[j] = ~pruned & viol;
         anyAct |= act[j];
-        chain[j] = 0;
-        nt[j] = 0x00010001u;              // tokens the leaf emits when live: its code, then the grown branch
     }
     cpk |= ((wa | (wa >> 16)) & 0xFFFFu) | ((wb | (wb >> 16)) << 16);
     const int nsteps = maxDepth - D;      // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
@@ -921,13 +952,10 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
             const uint32_t gt = pk_u((pk_s(tol2) - mm) >> 15);                                 // err > tol: grow
             nt[j] = pk_u(pk_s(nt[j]) - pk_s(act[j]));                                          // a code or the terminator
             const uint32_t go = act[j] & gt;
-            const uint32_t term = (act[j] ^ go) & 0x00030003u;                                 // R.cpp:699-703
             const uint32_t lim = (sg[j] & T2[j]) | (~sg[j] & (T2[j] ^ 0x00FF00FFu));
             const vr_s16x2 x = __builtin_elementwise_min(pk_s(d2) - mm, pk_s(lim));
             const vr_s16x2 nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
             const uint32_t take = go & pk_u((ax - mm) >> 15);
-            const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[j]));                        // add = 1, sub = 2
-            chain[j] |= ((take & dir) | term) << (2 * i);
             m[j] = (take & pk_u(ax)) | (~take & m[j]);
             sg[j] ^= take & pk_u(nx >> 15);
             act[j] = go;
@@ -949,16 +977,6 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         uint32_t q = *(const uint32_t *)(CR + (li >> 2));
         q |= (cpk & (cpk >> 1) & 0x55555555u) * 3u;     // every pruned leaf: range code 3 as well (M.cpp:864-865)
         *(uint32_t *)(CR + (li >> 2)) = q;
-    }
-    if (chainLo) {              // the grown branches, for k_emit4: 14 bits per leaf as two byte planes
-        uint32_t lo[4], hi[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            lo[q] = __builtin_amdgcn_perm(chain[2 * q + 1], chain[2 * q], 0x06040200u);
-            hi[q] = __builtin_amdgcn_perm(chain[2 * q + 1], chain[2 * q], 0x07050301u);
-        }
-        *(uint4 *)(rb.b[c.ra] + (int64_t)brick * leafStride + base + t * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-        *(uint4 *)(rb.b[c.rb] + (int64_t)brick * leafStride + base + t * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     }
     unsigned long long l1w = l1After;
     for (int o = 32; o > 0; o >>= 1) {
@@ -1120,6 +1138,7 @@ struct EmitArgs {
     uint32_t *idxOff;
     uint8_t *idxVal;
     int64_t nIdx;
+    const uint32_t *chainLut;
 };
 
 __device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t *shWave, uint32_t &total)
@@ -1302,10 +1321,10 @@ __device__ __forceinline__ void str_put(Str128 &s, uint32_t bits, int ntok)
 struct Quad { Str128 s; int preDs, aliveAtDs; };
 
 // inner: codes of the block's internal nodes at depths D-10 .. D-3, heap-ordered (node (l, i) at (1<<l)+i)
-// chLo/chHi: the leaves' grown branches as k_prune12 left them (14 bits per leaf, two byte planes)
-__device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ chLo,
-                                   const uint8_t *__restrict__ chHi, const uint8_t *inner, bool rootLive,
-                                   unsigned long long upSpine, int D, int maxDepth, int Ds, uint32_t r0)
+// lutS: k_chain_lut's table (LDS copy)
+__device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ Tb,
+                                   const uint8_t *__restrict__ Rl, const uint8_t *inner, const uint32_t *lutS, bool rootLive,
+                                   unsigned long long upSpine, int D, int maxDepth, int tol, int Ds, uint32_t r0)
 {
     Quad Q;
     Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0;
@@ -1317,9 +1336,8 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
     const uint32_t pair = (pk2 & 3u) | ((pk2 >> 2) << 8);
     const uint32_t clb = Cb[(((int64_t)1 << D) + r0) >> 2];                          // my four leaf codes = one byte
     const uint32_t cl = (clb & 3u) | (((clb >> 2) & 3u) << 8) | (((clb >> 4) & 3u) << 16) | (((clb >> 6) & 3u) << 24);
-    const uint32_t hl = *(const uint32_t *)(chLo + r0);
-    const uint32_t hh = *(const uint32_t *)(chHi + r0);
-    const int nsteps = maxDepth - D;
+    const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
+    const uint32_t rl = *(const uint32_t *)(Rl + r0);
     bool alive;
     int j;
     if (lr == 0) {                            // first rank of the block: the spine above depth D-10 comes precomputed
@@ -1355,10 +1373,27 @@ __device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t
             uint32_t bits = code;
             int nt = 1;
             if (code != 3) {                                         // grown branch, R.cpp:655-704
-                const uint32_t ch = ((hl >> (8 * k)) & 255u) | (((hh >> (8 * k)) & 255u) << 8);
-                const uint32_t t3 = ch & (ch >> 1) & 0x1555u;        // the terminator, if the branch has one
-                nt += t3 ? ((__ffs((int)t3) - 1) >> 1) + 1 : nsteps;
-                bits |= ch << 2;
+                const int t = (int)((tl >> (8 * k)) & 255u);
+                int rec = (int)((rl >> (8 * k)) & 255u);
+                const int m0 = rec > t ? rec - t : t - rec, lim = t < 255 - t ? t : 255 - t;
+                if (m0 <= lim) {                                     // no clamp can matter: table (see k_chain_lut)
+                    const uint32_t e = lutS[m0];
+                    const uint32_t ch = e & 0x3FFFu;
+                    bits |= (t > rec ? ch : chain_mirror(ch)) << 2;
+                    nt += (int)((e >> 14) & 7u);
+                } else {
+                    int depth = D;
+                    while (depth < maxDepth) {
+                        const int err = rec > t ? rec - t : t - rec;
+                        if (err > tol) {
+                            ++depth;
+                            const Enc en = encode_node(t, rec, 64 >> (depth - D - 1));   // distanceMap[D+1..] = 64 .. 1
+                            rec = en.recon;
+                            bits |= (uint32_t)en.code << (2 * nt);
+                            ++nt;
+                        } else { bits |= 3u << (2 * nt); ++nt; break; }
+                    }
+                }
             }
             str_put(Q.s, bits, nt);
         }
@@ -1415,10 +1450,11 @@ k_emit4(EmitArgs a)
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
-    const uint8_t *chLo = a.rb.b[c.ra] + (int64_t)brick * a.leafStride;   // k_prune12's branch records live in the two
-    const uint8_t *chHi = a.rb.b[c.rb] + (int64_t)brick * a.leafStride;   // reconstruction buffers the level loop left free
+    const uint8_t *Tb = a.temp + (int64_t)brick * a.heapStride;
+    const uint8_t *Rl = a.rb.b[c.par] + (int64_t)brick * a.leafStride;
     const uint32_t r0 = blockIdx.x * EMIT4_RANKS + threadIdx.x * 4;
     __shared__ uint8_t inner[256];
+    __shared__ uint32_t lutS[256];
     const int64_t bo = (int64_t)brick * a.nEmitBlk + blockIdx.x;
     const int bflags = a.blockAlive[bo];
     const int bval = a.blockVal[bo];
@@ -1437,9 +1473,10 @@ k_emit4(EmitArgs a)
         const int l = 31 - __clz(t);
         inner[t] = (uint8_t)cget(Cb, ((int64_t)1 << (a.D - 10 + l)) + (((int64_t)blockIdx.x) << l) + (t - (1 << l)));
     }
+    lutS[threadIdx.x] = a.chainLut[threadIdx.x];
     if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
     __syncthreads();
-    const Quad Q = quad_tokens(Cb, chLo, chHi, inner, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.Ds, r0);
+    const Quad Q = quad_tokens(Cb, Tb, Rl, inner, lutS, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.tol, a.Ds, r0);
     uint32_t tot;
     const uint32_t lo = block_excl_scan_u32((uint32_t)Q.s.n, shw, tot);
     if (!WRITE) {
@@ -1670,6 +1707,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipEventRecord(bs->ev[2], st);
     dbg_sync(st, "compress");
     // ---- PRUNE
+    hipLaunchKernelGGL(k_chain_lut, dim3(1), dim3(256), 0, st, bs->tolerance, bs->maxDepth - D, bs->chainLut);
     ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     int pruneFrom = D - 1;
@@ -1678,7 +1716,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
                            bs->codeStride, rb, bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
                            bs->nEmitBlk,    // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
-                           (!mr && bs->K >= 2) ? bs->blockL1 : nullptr, (!mr && bs->K >= 2) ? 1 : 0);
+                           (!mr && bs->K >= 2) ? bs->blockL1 : nullptr, bs->chainLut);
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
@@ -1704,6 +1742,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
+    a.chainLut = bs->chainLut;
     const bool quad = !mr && D >= 12 && bs->K >= 2;
     const int64_t nblk = cdiv((int64_t)1 << D, quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK);
     if (quad) hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);   // + token counts
