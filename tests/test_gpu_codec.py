@@ -38,6 +38,7 @@ def check_case(vr, O, vol, tol, ep, variant=0):
     assert info["num_reverts"] == ref.numReverts
     st = ref.leaf_stats()
     assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"]
+    assert abs(info["mean_l1_after"] - st["l1_after"]) < 1e-12
     dec = bs.decode().cpu().numpy().reshape(z, y, x)
     assert np.array_equal(dec, ref.levelCut())
     return ref, bs
@@ -165,6 +166,9 @@ def test_midrange_tree(vr, oracle):
     assert np.array_equal(t.tree, ref.tree)
     assert np.array_equal(t.tree_range, ref.tree_range)
     assert list(t.distanceMap_range) == list(ref.distanceMap_range)
+    info, st = t._bs.info(0), ref.leaf_stats()        # D = 15: the 12-level prune kernel with a range stream
+    assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"]
+    assert abs(info["mean_l1_after"] - st["l1_after"]) < 1e-12
     pk = t.convertToByteArray()
     assert np.array_equal(pk, ref.convertToByteArray())
     assert "%016x" % oracle.fnv1a64(pk) == "d363bd19dd90d0fd"     # SURVEY Appendix B known answer

@@ -781,6 +781,17 @@ __global__ void k_level_end(int d, Ctrl *ctrls)
 
 // The range stream's prune follows the mid stream (M.cpp:864-865); see k_prune_*.
 // ------------------------------------------------------------------ prune ----
+// per-block statistics record: sum |recon - truth| after growth (40 bits) | max error before << 40 | max after << 48
+__device__ __forceinline__ unsigned long long stat_pack(unsigned long long l1, int maxBefore, int maxAfter)
+{
+    return l1 | ((unsigned long long)maxBefore << 40) | ((unsigned long long)maxAfter << 48);
+}
+__device__ __forceinline__ unsigned long long stat_merge(unsigned long long a, unsigned long long b)
+{
+    const unsigned long long M40 = (1ull << 40) - 1ull;
+    const unsigned long long mb = max((a >> 40) & 255ull, (b >> 40) & 255ull), ma = max((a >> 48) & 255ull, (b >> 48) & 255ull);
+    return ((a & M40) + (b & M40)) | (mb << 40) | (ma << 48);
+}
 __global__ void __launch_bounds__(256)
 k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes,
              uint8_t *__restrict__ codesRange, int64_t heapStride, int64_t codeStride, ReconBufs rb, int64_t leafStride,
@@ -823,14 +834,12 @@ k_prune_leaf(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint
         int w = __shfl_xor(fm, o); fm = w > fm ? w : fm;
         l1 += __shfl_xor(l1, o);
     }
-    // one contended atomic per wave would serialise the whole grid: only waves that raise the max try
-    if ((threadIdx.x & 63) == 0) {
-        if (err > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, err); // R.cpp:71-76
-        if (fm > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, fm);     // R.cpp:115-120
-        shl[threadIdx.x >> 6] = l1;
-    }
+    // statistics leave as per-block records (no atomics on the brick's control block: every wave of a
+    // brick hitting one address serialises on one L2 channel); k_emit_stats reduces them
+    if ((threadIdx.x & 63) == 0) shl[threadIdx.x >> 6] = stat_pack(l1, err, fm);    // R.cpp:71-76, 115-129
     __syncthreads();
-    if (threadIdx.x == 0) blockL1[(int64_t)brick * nEmitBlk + blockIdx.x] = shl[0] + shl[1] + shl[2] + shl[3];
+    if (threadIdx.x == 0)
+        blockL1[(int64_t)brick * nEmitBlk + blockIdx.x] = stat_merge(stat_merge(shl[0], shl[1]), stat_merge(shl[2], shl[3]));
 }
 
 __global__ void __launch_bounds__(256)
@@ -984,11 +993,8 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         int w = __shfl_xor(maxAfter, o); maxAfter = w > maxAfter ? w : maxAfter;
         l1w += __shfl_xor(l1w, o);
     }
-    if ((t & 63) == 0) {
-        if (maxErr > *(volatile int *)&c.maxErrBefore) atomicMax(&c.maxErrBefore, maxErr);
-        if (maxAfter > *(volatile int *)&c.maxErrAfter) atomicMax(&c.maxErrAfter, maxAfter);
-        if (blockL1) blockL1[(int64_t)brick * nEmitBlk + (size_t)blockIdx.x * 4 + (t >> 6)] = l1w;   // one wave = 1024 leaves
-    }
+    if ((t & 63) == 0)      // one record per wave = 1024 leaves
+        blockL1[(int64_t)brick * nEmitBlk + (size_t)blockIdx.x * 4 + (t >> 6)] = stat_pack(l1w, maxErr, maxAfter);
     // level D-1: 8 nodes per thread, children flags in registers
     {
         const int64_t ni = ((int64_t)1 << (D - 1)) + (base >> 1) + t * 8;
@@ -1536,11 +1542,18 @@ k_emit_stats(EmitArgs a, int64_t nblk)
     const int brick = blockIdx.x;
     if (a.ctrls[brick].constBrick) return;
     unsigned long long v = 0;
-    for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) v += a.blockL1[(int64_t)brick * a.nEmitBlk + i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) v = stat_merge(v, a.blockL1[(int64_t)brick * a.nEmitBlk + i]);
+    for (int o = 32; o > 0; o >>= 1) v = stat_merge(v, __shfl_xor(v, o));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += sh[i]; a.ctrls[brick].statL1 = t; }
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; ++i) t = stat_merge(t, sh[i]);
+        Ctrl &c = a.ctrls[brick];
+        c.statL1 = t & ((1ull << 40) - 1ull);
+        c.maxErrBefore = (int)((t >> 40) & 255ull);
+        c.maxErrAfter = (int)((t >> 48) & 255ull);
+    }
 }
 
 // Closed form for a brick of one value v (tolerance >= 1, maxEpochs >= 1, D >= 1): the root's
@@ -1716,7 +1729,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
                            bs->codeStride, rb, bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
                            bs->nEmitBlk,    // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
-                           (!mr && bs->K >= 2) ? bs->blockL1 : nullptr, bs->chainLut);
+                           bs->blockL1, bs->chainLut);
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
@@ -1753,7 +1766,8 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
     if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, nblk);
+    // statistics records: one per 1024 leaves from k_prune12, one per 256 from k_prune_leaf
+    hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, (int64_t)(D >= 12 ? cdiv((int64_t)1 << D, 1024) : cdiv((int64_t)1 << D, 256)));
     hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.tree,
                        bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
     hipEventRecord(bs->ev[4], st);
