@@ -901,17 +901,29 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
     const uint32_t base = blockIdx.x << 12;
     uint8_t *Cb = codes + (int64_t)brick * codeStride;
     uint8_t *CR = codesRange ? codesRange + (int64_t)brick * codeStride : nullptr;
-    lutS[t] = chainLut[t];
-    for (int h = 1 + t; h < 2048; h += 256) {
+    // every global load of the block is issued before any is looked at (one memory round trip)
+    const uint32_t lutV = chainLut[t];
+    uint32_t lvB[8];
+    int lvSh[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int h = q * 256 + (t ? t : (q ? 0 : 1));           // heap index inside the block (index 0 is unused)
         const int lq = 31 - __clz(h);
-        const uint8_t cv0 = (uint8_t)cget(Cb, ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq)));
-        lv[h] = cv0;
-        lvOld[h] = cv0;
+        const int64_t ni = ((int64_t)1 << (D - 12 + lq)) + (((int64_t)blockIdx.x) << lq) + (h - (1 << lq));
+        lvB[q] = Cb[ni >> 2];
+        lvSh[q] = (int)(ni & 3) * 2;
     }
     const int64_t li = ((int64_t)1 << D) + base + t * 16;
     uint32_t cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
     const uint4 tv = *(const uint4 *)(temp + (int64_t)brick * heapStride + li);
     const uint4 rv = *(const uint4 *)(rb.b[c.par] + (int64_t)brick * leafStride + base + t * 16);
+    lutS[t] = lutV;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int h = q * 256 + t;
+        const uint8_t cv0 = (uint8_t)((lvB[q] >> lvSh[q]) & 3u);
+        if (h) { lv[h] = cv0; lvOld[h] = cv0; }
+    }
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
     // Sibling leaves 2j, 2j+1 share a packed 16-bit register pair.  State of a leaf: m = |truth - recon|,
     // sg = 0xFFFF where truth < recon.  One step of the grown branch with distance d (encodeNode with the
@@ -1328,22 +1340,32 @@ struct Quad { Str128 s; int preDs, aliveAtDs; };
 
 // inner: codes of the block's internal nodes at depths D-10 .. D-3, heap-ordered (node (l, i) at (1<<l)+i)
 // lutS: k_chain_lut's table (LDS copy)
-__device__ inline Quad quad_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ Tb,
-                                   const uint8_t *__restrict__ Rl, const uint8_t *inner, const uint32_t *lutS, bool rootLive,
+// What a thread reads from memory for its quad, fetched in one batch before anything is looked at
+struct QuadIn { uint32_t quadB, pairB, clb, tl, rl; };
+__device__ __forceinline__ QuadIn quad_load(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ Tb,
+                                            const uint8_t *__restrict__ Rl, int D, uint32_t r0)
+{
+    QuadIn q;
+    q.quadB = Cb[(((int64_t)1 << (D - 2)) + (r0 >> 2)) >> 2];      // byte holding the depth-(D-2) code
+    q.pairB = Cb[(((int64_t)1 << (D - 1)) + (r0 >> 1)) >> 2];      // 4 packed depth-(D-1) codes
+    q.clb = Cb[(((int64_t)1 << D) + r0) >> 2];                      // my four leaf codes = one byte
+    q.tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
+    q.rl = *(const uint32_t *)(Rl + r0);
+    return q;
+}
+
+__device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const uint32_t *lutS, bool rootLive,
                                    unsigned long long upSpine, int D, int maxDepth, int tol, int Ds, uint32_t r0)
 {
     Quad Q;
     Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0;
     const uint32_t lr = r0 & 1023u;                                  // rank inside the block
-    // every global load is issued before any is looked at: one memory latency, no dependent chain
-    const int quadCode = cget(Cb, ((int64_t)1 << (D - 2)) + (r0 >> 2));
-    const uint32_t pairB = Cb[(((int64_t)1 << (D - 1)) + (r0 >> 1)) >> 2];          // 4 packed depth-(D-1) codes
-    const uint32_t pk2 = (pairB >> (((r0 >> 1) & 3u) * 2u)) & 15u;                   // mine: two of them
+    const int quadCode = (int)((in.quadB >> (((r0 >> 2) & 3u) * 2u)) & 3u);
+    const uint32_t pk2 = (in.pairB >> (((r0 >> 1) & 3u) * 2u)) & 15u;                // mine: two of the four
     const uint32_t pair = (pk2 & 3u) | ((pk2 >> 2) << 8);
-    const uint32_t clb = Cb[(((int64_t)1 << D) + r0) >> 2];                          // my four leaf codes = one byte
+    const uint32_t clb = in.clb;
     const uint32_t cl = (clb & 3u) | (((clb >> 2) & 3u) << 8) | (((clb >> 4) & 3u) << 16) | (((clb >> 6) & 3u) << 24);
-    const uint32_t tl = *(const uint32_t *)(Tb + ((int64_t)1 << D) + r0);
-    const uint32_t rl = *(const uint32_t *)(Rl + r0);
+    const uint32_t tl = in.tl, rl = in.rl;
     bool alive;
     int j;
     if (lr == 0) {                            // first rank of the block: the spine above depth D-10 comes precomputed
@@ -1473,23 +1495,26 @@ k_emit4(EmitArgs a)
         }
         return;
     }
-    // the block's internal nodes of depths D-10 .. D-3 (255 codes) into LDS, one per thread
-    if (threadIdx.x >= 1) {
-        const int t = threadIdx.x;                    // heap index inside the block: 1 .. 255
-        const int l = 31 - __clz(t);
-        inner[t] = (uint8_t)cget(Cb, ((int64_t)1 << (a.D - 10 + l)) + (((int64_t)blockIdx.x) << l) + (t - (1 << l)));
-    }
-    lutS[threadIdx.x] = a.chainLut[threadIdx.x];
+    // every global load of the block is issued here, before any is looked at (one memory round trip
+    // instead of a chain of them): the block's internal nodes of depths D-10 .. D-3 (255 codes, one per
+    // thread, heap index t inside the block), the branch table, the quad's own bytes, the block offset
+    const int t = threadIdx.x ? threadIdx.x : 1, l = 31 - __clz(t);
+    const int64_t innerIdx = ((int64_t)1 << (a.D - 10 + l)) + (((int64_t)blockIdx.x) << l) + (t - (1 << l));
+    const uint32_t innerB = Cb[innerIdx >> 2];
+    const uint32_t lutV = a.chainLut[threadIdx.x];
+    const QuadIn qin = quad_load(Cb, Tb, Rl, a.D, r0);
+    const uint32_t g0 = WRITE ? a.blockOff[bo] : 0u;
+    inner[threadIdx.x] = (uint8_t)((innerB >> ((int)(innerIdx & 3) * 2)) & 3u);
+    lutS[threadIdx.x] = lutV;
     if (WRITE) for (int i = threadIdx.x; i < EMIT4_LDS_WORDS; i += 256) W[i] = 0;
     __syncthreads();
-    const Quad Q = quad_tokens(Cb, Tb, Rl, inner, lutS, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.tol, a.Ds, r0);
+    const Quad Q = quad_tokens(qin, inner, lutS, (bflags & 2) != 0, upSpine, a.D, a.maxDepth, a.tol, a.Ds, r0);
     uint32_t tot;
     const uint32_t lo = block_excl_scan_u32((uint32_t)Q.s.n, shw, tot);
     if (!WRITE) {
         if (threadIdx.x == 0) a.blockTot[(int64_t)brick * a.nEmitBlk + blockIdx.x] = tot;
         return;
     }
-    const uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blockIdx.x];
     const uint32_t phase = g0 & 15u;
     // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
     // would be a bug; it must surface as a failed parity check, not as a memory fault)
