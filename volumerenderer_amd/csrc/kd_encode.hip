@@ -278,8 +278,13 @@ __global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *
 #define EST_ROUNDS 4        // round 0 uses a 4-wide window, later rounds EST_CAND-wide recentred ones
 #define EST_HEAD 4096
 
-struct EstSummary { uint32_t sumS[EST_CAND], sumC[EST_CAND]; int32_t A[EST_CAND], B[EST_CAND]; };
-static_assert(sizeof(EstSummary) == 16 * EST_CAND, "EstSummary layout");
+// Segment summaries of one brick, structure of arrays: field f of candidate ci of segment seg lives at
+// ((f * EST_CAND + ci) * summStride + seg), so the walking wave reads 64 consecutive segments as one line.
+enum { EST_F_SUMS = 0, EST_F_SUMC = 1, EST_F_A = 2, EST_F_B = 3 };
+__device__ __forceinline__ int64_t est_at(int f, int ci, int64_t summStride, uint32_t seg)
+{
+    return (int64_t)(f * EST_CAND + ci) * summStride + seg;
+}
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
@@ -370,13 +375,14 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
 // pd > h, so under the hypothesis floor(S/(2C+1)) == Th node k counts  <=>  pd_k > min(Th, h_k).
 __global__ void __launch_bounds__(256)
 k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
-           int64_t leafStride, EstSummary *__restrict__ summ, int64_t summStride)
+           int64_t leafStride, uint32_t *__restrict__ summ, int64_t summStride)
 {
     const int brick = blockIdx.y, lane = threadIdx.x & 63;
     const Ctrl &c = ctrls[brick];
     const uint32_t n = 1u << d;
-    const uint32_t seg = EST_HEAD / EST_SEG + blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c.constBrick || c.estDone || seg < (uint32_t)c.estSeg || seg >= n / EST_SEG) return;
+    if (c.constBrick || c.estDone) return;
+    // segments from where the walk stands; later rounds run on a small grid (most bricks are done by then)
+    for (uint32_t seg = (uint32_t)c.estSeg + blockIdx.x * 4 + (threadIdx.x >> 6); seg < n / EST_SEG; seg += gridDim.x * 4) {
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + (size_t)seg * EST_SEG + lane * 16;
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride + (((size_t)seg * EST_SEG + lane * 16) >> 1);
     const uint4 tv = *(const uint4 *)T;
@@ -396,10 +402,10 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         anyPd |= pk_u(pd[k]);
     }
     const int Tbase = c.estTbase;
-    EstSummary *out = summ + (int64_t)brick * summStride + seg;
+    uint32_t *out = summ + (int64_t)brick * summStride * (4 * EST_CAND);
     if (__ballot(anyPd != 0) == 0ull) {      // parents reproduce the truths exactly (constant regions): nothing counts
-        if (lane < nc) { out->sumS[lane] = 0; out->sumC[lane] = 0; out->A[lane] = 0; out->B[lane] = 0; }
-        return;
+        if (lane < 4 * nc) out[est_at(lane / nc, lane % nc, summStride, seg)] = 0;
+        continue;
     }
 #pragma unroll 1
     for (int ci = 0; ci < nc; ++ci) {
@@ -431,20 +437,26 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         a = wave_max_i32_dpp(a);
         b = -wave_max_i32_dpp(-b);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (lane == 0) { out->sumS[ci] = tot & 0xFFFFFu; out->sumC[ci] = tot >> 20; out->A[ci] = a; out->B[ci] = b; }
+        if (lane == 0) {
+            out[est_at(EST_F_SUMS, ci, summStride, seg)] = tot & 0xFFFFFu;
+            out[est_at(EST_F_SUMC, ci, summStride, seg)] = tot >> 20;
+            out[est_at(EST_F_A, ci, summStride, seg)] = (uint32_t)a;
+            out[est_at(EST_F_B, ci, summStride, seg)] = (uint32_t)b;
+        }
+    }
     }
 }
 
 __global__ void __launch_bounds__(64)
 k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
-           int64_t leafStride, const EstSummary *__restrict__ summ, int64_t summStride)
+           int64_t leafStride, const uint32_t *__restrict__ summ, int64_t summStride)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
     const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
     const uint32_t n = 1u << d, nseg = n / EST_SEG;
-    const EstSummary *sm = summ + (int64_t)brick * summStride;
+    const uint32_t *sm = summ + (int64_t)brick * summStride * (4 * EST_CAND);
     if (c.constBrick || c.estDone) return;
     unsigned long long S = c.estS;
     uint32_t C = c.estC;
@@ -452,6 +464,10 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
     long long Tc = (long long)(S / (2ull * C + 1ull));
     uint32_t seg = (uint32_t)c.estSeg;
     int fallbacks = 0;
+    // the next 64 records are fetched while the current ones are checked (same candidate: the common case)
+    uint32_t preSeg = 0xFFFFFFFFu, preS = 0, preC = 0;
+    long long preCi = -1;
+    int preA = 0, preB = 0;
     while (seg < nseg) {
         const long long ci = Tc - Tbase;
         if (ci < 0 || ci >= nc) {            // threshold left the candidate window
@@ -471,7 +487,19 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
         const bool valid = k < nseg;
         uint32_t ss = 0, sc = 0;
         int A = INT32_MIN, B = INT32_MAX;
-        if (valid) { ss = sm[k].sumS[ci]; sc = sm[k].sumC[ci]; A = sm[k].A[ci]; B = sm[k].B[ci]; }
+        if (preSeg == seg && preCi == ci) { ss = preS; sc = preC; A = preA; B = preB; }
+        else if (valid) {
+            ss = sm[est_at(EST_F_SUMS, (int)ci, summStride, k)]; sc = sm[est_at(EST_F_SUMC, (int)ci, summStride, k)];
+            A = (int)sm[est_at(EST_F_A, (int)ci, summStride, k)]; B = (int)sm[est_at(EST_F_B, (int)ci, summStride, k)];
+        }
+        {
+            const uint32_t k2 = k + 64;
+            preSeg = seg + 64; preCi = ci; preS = 0; preC = 0; preA = INT32_MIN; preB = INT32_MAX;
+            if (k2 < nseg) {
+                preS = sm[est_at(EST_F_SUMS, (int)ci, summStride, k2)]; preC = sm[est_at(EST_F_SUMC, (int)ci, summStride, k2)];
+                preA = (int)sm[est_at(EST_F_A, (int)ci, summStride, k2)]; preB = (int)sm[est_at(EST_F_B, (int)ci, summStride, k2)];
+            }
+        }
         const uint32_t si = wave_incl_scan_u32(ss, lane), sci = wave_incl_scan_u32(sc, lane);
         const long long S0 = (long long)S + (long long)(si - ss);
         const long long q = 2ll * ((long long)C + (long long)(sci - sc)) + 1ll;
@@ -689,9 +717,10 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
         const int dist = (int)(uint8_t)c.currentDistance;
         const uint32_t nblk = (n + FILL_NODES_PER_BLOCK - 1) / FILL_NODES_PER_BLOCK;
         const unsigned long long *be = blockErr + (int64_t)brick * nErrBlk;
-        for (uint32_t base = 0; base < nblk; base += 64) {
-            const uint32_t blk = base + lane;
-            const unsigned long long e2 = blk < nblk ? be[blk] : 0ull;
+        unsigned long long pre = (uint32_t)lane < nblk ? be[lane] : 0ull;     // the next 64 partials are in flight
+        for (uint32_t base = 0; base < nblk; base += 64) {                  // while these are added
+            const unsigned long long e2 = pre;
+            pre = base + 64 + lane < nblk ? be[base + 64 + lane] : 0ull;
             unsigned long long incl = e2;
             for (int o = 1; o < 64; o <<= 1) { unsigned long long u = __shfl_up(incl, o); if (lane >= o) incl += u; }
             const unsigned long long total = __shfl(incl, 63);
@@ -1629,11 +1658,12 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
             for (int r = 0; r < EST_ROUNDS; ++r) {
                 const int nc = r == 0 ? 4 : EST_CAND;
-                hipLaunchKernelGGL(k_est_summ, dim3(cdiv(nseg, 4), B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
-                                   bs->heapStride, rb, bs->leafStride, (EstSummary *)bs->estSumm, bs->estSummStride);
+                const unsigned gx = r == 0 ? cdiv(nseg, 4) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);
+                hipLaunchKernelGGL(k_est_summ, dim3(gx, B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
+                                   bs->heapStride, rb, bs->leafStride, (uint32_t *)bs->estSumm, bs->estSummStride);
                 hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, EST_CAND,
                                    r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
-                                   (const EstSummary *)bs->estSumm, bs->estSummStride);
+                                   (const uint32_t *)bs->estSumm, bs->estSummStride);
             }
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
