@@ -288,19 +288,25 @@ __device__ __forceinline__ int64_t est_at(int f, int ci, int64_t summStride, uin
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
-    for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(v, o); if (lane >= o) v += u; }
-    return v;
+    (void)lane;
+    return wave_incl_scan_add_dpp(v);      // DPP network: no LDS-crossbar round trips in the serial walks
 }
 
 // exact in-order walk of nodes [lo, hi) by one wave; (S,C) are wave-uniform
 __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, uint32_t lo,
                                        uint32_t hi, unsigned long long &S, uint32_t &C, int lane)
 {
+    // the next 64 nodes are in flight while these are decided (the walk is latency-bound otherwise)
+    int tn = lo + lane < hi ? T[lo + lane] : 0, pn = (lo + lane < hi && d > 0) ? P[(lo + lane) >> 1] : 0;
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t i = base + lane;
         bool valid = i < hi;
-        int t = valid ? T[i] : 0;
-        int p = (valid && d > 0) ? P[i >> 1] : 0;
+        const int t = tn, p = pn;
+        {
+            const uint32_t i2 = i + 64;
+            tn = i2 < hi ? T[i2] : 0;
+            pn = (i2 < hi && d > 0) ? P[i2 >> 1] : 0;
+        }
         int pd = p > t ? p - t : t - p;
         bool forced = (t > p && 2 * t - p > 255) || (t < p && 2 * t < p);
         bool cand = valid && pd > 0;
@@ -673,11 +679,17 @@ __device__ __forceinline__ double next_pow2_above(double s)
 __device__ inline double ctl_walk_block(double s, const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d,
                                         int dist, uint32_t lo, uint32_t hi, int lane)
 {
+    int tn = lo + lane < hi ? T[lo + lane] : 0, pn = (lo + lane < hi && d > 0) ? P[(lo + lane) >> 1] : 0;   // one step ahead
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t i = base + lane;
         uint32_t e = 0;
+        const int t = tn, p = pn;
+        {
+            const uint32_t i2 = i + 64;
+            tn = i2 < hi ? T[i2] : 0;
+            pn = (i2 < hi && d > 0) ? P[i2 >> 1] : 0;
+        }
         if (i < hi) {
-            int t = T[i], p = d > 0 ? P[i >> 1] : 0;
             int er = encode_node(t, p, dist).err;
             e = (uint32_t)(er * er);
         }
@@ -721,8 +733,9 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
         for (uint32_t base = 0; base < nblk; base += 64) {                  // while these are added
             const unsigned long long e2 = pre;
             pre = base + 64 + lane < nblk ? be[base + 64 + lane] : 0ull;
-            unsigned long long incl = e2;
-            for (int o = 1; o < 64; o <<= 1) { unsigned long long u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            // two 32-bit DPP scans (24-bit limbs: 64 partials of < 2^27 each cannot overflow either)
+            const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 & 0xFFFFFFull)) +
+                                            ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 >> 24)) << 24);
             const unsigned long long total = __shfl(incl, 63);
             unsigned long long consumed = 0;
             int start = 0;
@@ -1191,8 +1204,7 @@ struct EmitArgs {
 __device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t *shWave, uint32_t &total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t incl = v;
-    for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    const uint32_t incl = wave_incl_scan_add_dpp(v);
     if (lane == 63) shWave[w] = incl;
     __syncthreads();
     uint32_t woff = 0, tot = 0;
