@@ -1407,11 +1407,17 @@ __device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const
     const uint32_t clb = in.clb;
     const uint32_t cl = (clb & 3u) | (((clb >> 2) & 3u) << 8) | (((clb >> 4) & 3u) << 16) | (((clb >> 6) & 3u) << 24);
     const uint32_t tl = in.tl, rl = in.rl;
+    // The thread's string = spine (the live ancestors above the quad node whose first leaf is r0; at most
+    // D-2 <= 26 tokens, one 64-bit word) followed by the quad node's subtree, composed bottom-up from
+    // fixed-shape pieces: leaf = code + branch (<= 8 tokens), half = pair node + two leaves (<= 17 tokens),
+    // quad = node + two halves (<= 35 tokens).  Three wide shifts per thread instead of one per token.
     bool alive;
     int j;
+    unsigned long long S = 0;
+    int ns = 0;
     if (lr == 0) {                            // first rank of the block: the spine above depth D-10 comes precomputed
-        const int nsp = (int)(upSpine >> 56);
-        if (nsp) { Q.s.lo = upSpine & 0x00FFFFFFFFFFFFFFull; Q.s.n = nsp; }
+        ns = (int)(upSpine >> 56);
+        S = upSpine & 0x00FFFFFFFFFFFFFFull;
         alive = rootLive;
         j = D - 10;
     } else {
@@ -1420,53 +1426,74 @@ __device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const
         const int l = j - 1 - (D - 10);       // parent level inside the block
         alive = inner[(1 << l) + (lr >> (D - j + 1))] != 3;
     }
-    for (; alive && j <= D - 2; ++j) {         // spine down to the quad's depth-(D-2) node
-        if (j == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
+    for (; alive && j <= D - 3; ++j) {         // spine down to the quad node's parent
+        if (j == Ds) { Q.preDs = ns; Q.aliveAtDs = 1; }
         const int l = j - (D - 10);
-        const int code = j == D - 2 ? quadCode : inner[(1 << l) + (lr >> (D - j))];
-        str_put(Q.s, (uint32_t)code, 1);
+        const uint32_t code = inner[(1 << l) + (lr >> (D - j))];
+        S |= (unsigned long long)code << (2 * ns);
+        ++ns;
         if (code == 3) alive = false;
     }
-    if (!alive) return Q;
+    unsigned long long qlo = 0, qhi = 0;
+    int qn = 0;
+    if (alive) {
+        if (D - 2 == Ds) { Q.preDs = ns; Q.aliveAtDs = 1; }      // (Ds <= D-2: the index granularity K is >= 2 here)
+        qlo = (unsigned long long)quadCode;
+        qn = 1;
+        if (quadCode != 3) {
+            unsigned long long H[2];
+            int Hn[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int pc = (pair >> (8 * h)) & 255;
-        if (h == 0 && D - 1 == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
-        str_put(Q.s, (uint32_t)pc, 1);
-        if (pc == 3) continue;
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t pc = (pair >> (8 * h)) & 255u;
+                H[h] = pc; Hn[h] = 1;
+                if (pc == 3) continue;
+                uint32_t Lb[2];
+                int Ln[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int k = 2 * h + e;
-            if (k == 0 && D == Ds) { Q.preDs = Q.s.n; Q.aliveAtDs = 1; }
-            const uint32_t code = (cl >> (8 * k)) & 255u;
-            uint32_t bits = code;
-            int nt = 1;
-            if (code != 3) {                                         // grown branch, R.cpp:655-704
-                const int t = (int)((tl >> (8 * k)) & 255u);
-                int rec = (int)((rl >> (8 * k)) & 255u);
-                const int m0 = rec > t ? rec - t : t - rec, lim = t < 255 - t ? t : 255 - t;
-                if (m0 <= lim) {                                     // no clamp can matter: table (see k_chain_lut)
-                    const uint32_t e = lutS[m0];
-                    const uint32_t ch = e & 0x3FFFu;
-                    bits |= (t > rec ? ch : chain_mirror(ch)) << 2;
-                    nt += (int)((e >> 14) & 7u);
-                } else {
-                    int depth = D;
-                    while (depth < maxDepth) {
-                        const int err = rec > t ? rec - t : t - rec;
-                        if (err > tol) {
-                            ++depth;
-                            const Enc en = encode_node(t, rec, 64 >> (depth - D - 1));   // distanceMap[D+1..] = 64 .. 1
-                            rec = en.recon;
-                            bits |= (uint32_t)en.code << (2 * nt);
-                            ++nt;
-                        } else { bits |= 3u << (2 * nt); ++nt; break; }
+                for (int e = 0; e < 2; ++e) {
+                    const int k = 2 * h + e;
+                    const uint32_t code = (cl >> (8 * k)) & 255u;
+                    uint32_t bits = code;
+                    int nt = 1;
+                    if (code != 3) {                                         // grown branch, R.cpp:655-704
+                        const int t = (int)((tl >> (8 * k)) & 255u);
+                        int rec = (int)((rl >> (8 * k)) & 255u);
+                        const int m0 = rec > t ? rec - t : t - rec, lim = t < 255 - t ? t : 255 - t;
+                        if (m0 <= lim) {                                     // no clamp can matter: table (see k_chain_lut)
+                            const uint32_t en = lutS[m0];
+                            const uint32_t ch = en & 0x3FFFu;
+                            bits |= (t > rec ? ch : chain_mirror(ch)) << 2;
+                            nt += (int)((en >> 14) & 7u);
+                        } else {
+                            int depth = D;
+                            while (depth < maxDepth) {
+                                const int err = rec > t ? rec - t : t - rec;
+                                if (err > tol) {
+                                    ++depth;
+                                    const Enc en = encode_node(t, rec, 64 >> (depth - D - 1));   // distanceMap[D+1..] = 64 .. 1
+                                    rec = en.recon;
+                                    bits |= (uint32_t)en.code << (2 * nt);
+                                    ++nt;
+                                } else { bits |= 3u << (2 * nt); ++nt; break; }
+                            }
+                        }
                     }
+                    Lb[e] = bits; Ln[e] = nt;
                 }
+                H[h] = (unsigned long long)pc | ((unsigned long long)Lb[0] << 2) | ((unsigned long long)Lb[1] << (2 + 2 * Ln[0]));
+                Hn[h] = 1 + Ln[0] + Ln[1];
             }
-            str_put(Q.s, bits, nt);
+            const int sh1 = 2 + 2 * Hn[0];                  // 4 .. 36
+            qlo |= (H[0] << 2) | (H[1] << sh1);
+            qhi = H[1] >> (64 - sh1);
+            qn = 1 + Hn[0] + Hn[1];
         }
     }
+    const int shS = 2 * ns;                                 // <= 52
+    Q.s.lo = S | (qlo << shS);
+    Q.s.hi = (qhi << shS) | (shS ? qlo >> (64 - shS) : 0ull);
+    Q.s.n = ns + qn;
     return Q;
 }
 
