@@ -1367,16 +1367,6 @@ k_emit_write(EmitArgs a)
 #define EMIT4_LDS_WORDS 640     // >= (1024*8 + 1023 + 28 + 15) / 16
 
 struct Str128 { unsigned long long lo, hi; int n; };
-__device__ __forceinline__ void str_put(Str128 &s, uint32_t bits, int ntok)
-{
-    const int sh = 2 * s.n;
-    if (sh < 64) {
-        s.lo |= (unsigned long long)bits << sh;
-        if (sh > 32) s.hi |= (unsigned long long)bits >> (64 - sh);
-    } else s.hi |= (unsigned long long)bits << (sh - 64);
-    s.n += ntok;
-}
-
 struct Quad { Str128 s; int preDs, aliveAtDs; };
 
 // inner: codes of the block's internal nodes at depths D-10 .. D-3, heap-ordered (node (l, i) at (1<<l)+i)
