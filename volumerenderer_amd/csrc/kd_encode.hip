@@ -1214,6 +1214,285 @@ __device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t *shWave, uin
     return woff + incl - v;
 }
 
+// ---- prune + block-local emit (VolumeKdtree streams with D >= 12: K = 6, Ds = D-6) --------------
+// One block owns a depth-(D-12) subtree: 4096 leaves, 16 per thread.  It prunes the twelve levels
+// bottom-up like k_prune12 (the four above the leaves in registers, the other eight in LDS), and then,
+// top-down, writes the subtree's own preorder token string -- assuming its root is live -- into LDS
+// and from there into a per-block staging area.  k_concat12 later moves the strings of the live
+// blocks to their final offsets.  The leaf arrays are read once; the staging area is memory the level
+// loop has left free: the internal half of the midrange heap and the two spare reconstruction buffers
+// (4 KiB each per block; a block's string is at most 4095 + 8 * 4096 tokens = 9216 bytes).
+#define PE_WORDS 2320
+
+struct PruneEmitArgs {
+    int D, tol, maxDepth;
+    Ctrl *ctrls;
+    uint8_t *temp;                 // truths (leaf half, read) / staging (internal half, written)
+    uint8_t *codes;
+    int64_t heapStride, codeStride, leafStride;
+    ReconBufs rb;
+    uint32_t *subTok;              // tokens of the block's subtree (k_block_alive reads it from blockOff[])
+    int64_t nEmitBlk;
+    unsigned long long *blockL1;
+    const uint32_t *chainLut;
+    uint32_t *idxOff;              // block-local token offset of every depth-Ds node (k_concat12 makes it global)
+    int64_t nIdx;
+};
+
+__device__ __forceinline__ uint32_t *pe_stage(uint8_t *temp, int64_t heapStride, const ReconBufs &rb, int ra, int rbI,
+                                              int64_t leafStride, int brick, uint32_t blk, uint32_t w)
+{
+    uint8_t *basePtr = w < 1024u ? temp + (int64_t)brick * heapStride
+                                 : (w < 2048u ? rb.b[ra] : rb.b[rbI]) + (int64_t)brick * leafStride;
+    return (uint32_t *)(basePtr + (int64_t)blk * 4096) + (w & 1023u);
+}
+
+__device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
+{   // v: at most 44 bits of tokens
+    if (ntok <= 0) return;
+    const uint32_t sh = bitpos & 31u, w = bitpos >> 5;
+    const unsigned long long lo = v << sh;
+    atomicOr(&W[w], (uint32_t)lo);
+    if ((uint32_t)(lo >> 32)) atomicOr(&W[w + 1], (uint32_t)(lo >> 32));
+    const uint32_t hi = sh ? (uint32_t)(v >> (64u - sh)) : 0u;
+    if (hi) atomicOr(&W[w + 2], hi);
+}
+
+__global__ void __launch_bounds__(256)
+k_prune_emit12(PruneEmitArgs a)
+{
+    __shared__ uint32_t lutS[256];
+    __shared__ uint32_t W[PE_WORDS];
+    __shared__ uint8_t codeH[256], codeOldH[256];    // the block's nodes of depths D-12 .. D-5, heap order (1 .. 255)
+    __shared__ uint8_t flH[512];                     // "subtree is a single pruned token" flags; 256 + t = the depth-(D-4) nodes
+    __shared__ uint16_t cntH[512];                   // tokens a live subtree emits
+    __shared__ uint32_t shw[4];
+    const int brick = blockIdx.y, t = threadIdx.x, D = a.D, tol = a.tol;
+    Ctrl &c = a.ctrls[brick];
+    if (c.constBrick) return;
+    const uint32_t blk = blockIdx.x, base = blk << 12;
+    uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
+    // ---- every global load of the block, in one batch
+    const uint32_t lutV = a.chainLut[t];
+    const int hU = t ? t : 1, lqU = 31 - __clz(hU);
+    const int64_t niU = ((int64_t)1 << (D - 12 + lqU)) + ((int64_t)blk << lqU) + (hU - (1 << lqU));
+    const uint32_t upB = Cb[niU >> 2];
+    const int64_t n4 = ((int64_t)1 << (D - 4)) + (base >> 4) + t, n3 = ((int64_t)1 << (D - 3)) + (base >> 3) + 2 * t;
+    const int64_t n2 = ((int64_t)1 << (D - 2)) + (base >> 2) + 4 * t, n1 = ((int64_t)1 << (D - 1)) + (base >> 1) + 8 * t;
+    const uint32_t c4B = Cb[n4 >> 2], c3B = Cb[n3 >> 2], c2B = Cb[n2 >> 2];
+    const uint32_t c1H = *(const uint16_t *)(Cb + (n1 >> 2));
+    const int64_t li = ((int64_t)1 << D) + base + t * 16;
+    const uint32_t cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
+    const uint4 tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
+    const uint4 rv = *(const uint4 *)(a.rb.b[c.par] + (int64_t)brick * a.leafStride + base + t * 16);
+    lutS[t] = lutV;
+    { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
+    for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
+    __syncthreads();
+    // ---- leaves: prune (R.cpp:618-626), grown branches (R.cpp:655-704); sibling leaves share packed 16-bit lanes
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    const uint32_t tol2 = (uint32_t)tol * 0x10001u;
+    uint32_t T2[8], m[8], sg[8], act[8], nt[8], chain[8], lcode[8];
+    uint32_t bothMask = 0, anyAct = 0;
+    vr_s16x2 mxB = (vr_s16x2)(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
+        T2[j] = __builtin_amdgcn_perm(0, tw[j >> 1], sel);
+        const vr_s16x2 dl = pk_s(T2[j]) - pk_s(__builtin_amdgcn_perm(0, rw[j >> 1], sel));
+        const vr_s16x2 mm = pk_abs(dl);
+        m[j] = pk_u(mm);
+        sg[j] = pk_u(dl >> 15);
+        mxB = __builtin_elementwise_max(mxB, mm);
+        const uint32_t lt = pk_u((mm - pk_s(tol2)) >> 15);                                     // err < tol
+        const uint32_t cl2 = ((cpk >> (4 * j)) & 3u) | (((cpk >> (4 * j + 2)) & 3u) << 16);     // the pair's codes
+        const uint32_t isz = pk_u((pk_s(cl2) - pk_s(0x00010001u)) >> 15), is3 = pk_u((pk_s(0x00020002u) - pk_s(cl2)) >> 15);
+        const uint32_t newp = isz & lt;
+        const uint32_t pruned = newp | is3;
+        lcode[j] = cl2 | (newp & 0x00030003u);
+        bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
+        const vr_s16x2 lim = __builtin_elementwise_min(pk_s(T2[j]), pk_s(T2[j] ^ 0x00FF00FFu));
+        const uint32_t viol = pk_u((lim - mm) >> 15);                                          // a clamp could matter
+        const uint32_t e0 = lutS[m[j] & 255u], e1 = lutS[(m[j] >> 16) & 255u];
+        const uint32_t useL = ~pruned & ~viol;
+        const uint32_t ch2 = (e0 & 0x3FFFu) | ((e1 & 0x3FFFu) << 16);
+        const uint32_t mir = ch2 ^ (((ch2 ^ (ch2 >> 1)) & 0x15551555u) * 3u);                   // add <-> sub
+        chain[j] = useL & ((sg[j] & mir) | (~sg[j] & ch2));
+        nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
+        m[j] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[j]);
+        act[j] = ~pruned & viol;
+        anyAct |= act[j];
+    }
+    const int nsteps = a.maxDepth - D;    // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
+    for (int i = 0; i < nsteps; ++i) {    // exact stepping for the leaves the table does not cover
+        if (__ballot(anyAct != 0) == 0ull) break;
+        const uint32_t d2 = (uint32_t)(64 >> i) * 0x10001u;
+        anyAct = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const vr_s16x2 mm = pk_s(m[j]);
+            const uint32_t gt = pk_u((pk_s(tol2) - mm) >> 15);
+            nt[j] = pk_u(pk_s(nt[j]) - pk_s(act[j]));
+            const uint32_t go = act[j] & gt;
+            const uint32_t term = (act[j] ^ go) & 0x00030003u;                                 // R.cpp:699-703
+            const uint32_t lim = (sg[j] & T2[j]) | (~sg[j] & (T2[j] ^ 0x00FF00FFu));
+            const vr_s16x2 x = __builtin_elementwise_min(pk_s(d2) - mm, pk_s(lim));
+            const vr_s16x2 nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
+            const uint32_t take = go & pk_u((ax - mm) >> 15);
+            const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[j]));                        // add = 1, sub = 2
+            chain[j] |= ((take & dir) | term) << (2 * i);
+            m[j] = (take & pk_u(ax)) | (~take & m[j]);
+            sg[j] ^= take & pk_u(nx >> 15);
+            act[j] = go;
+            anyAct |= go;
+        }
+    }
+    {   // statistics (R.cpp:71-76, 115-129): one record per wave = 1024 leaves
+        vr_s16x2 mxA = (vr_s16x2)(0), l1p = (vr_s16x2)(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mxA = __builtin_elementwise_max(mxA, pk_s(m[j])); l1p += pk_s(m[j]); }
+        int maxErr = max((int)mxB.x, (int)mxB.y), maxAfter = max((int)mxA.x, (int)mxA.y);
+        unsigned long long l1w = (unsigned long long)((int)l1p.x + (int)l1p.y);
+        for (int o = 32; o > 0; o >>= 1) {
+            int u = __shfl_xor(maxErr, o); maxErr = u > maxErr ? u : maxErr;
+            int w = __shfl_xor(maxAfter, o); maxAfter = w > maxAfter ? w : maxAfter;
+            l1w += __shfl_xor(l1w, o);
+        }
+        if ((t & 63) == 0)
+            a.blockL1[(int64_t)brick * a.nEmitBlk + (size_t)blk * 4 + (t >> 6)] = stat_pack(l1w, maxErr, maxAfter);
+    }
+    // ---- depths D-1 .. D-4 of my 16 leaves, in registers (R.cpp:596-629: a node only depends on its children)
+    uint32_t a1 = c1H, a2 = c2B, f1 = 0, f2 = 0, f3m = 0;      // new codes (2 bits each), pruned-token flags
+    int cnt1[8], cnt2[4], cnt3[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t code = (a1 >> (2 * k)) & 3u;
+        const bool p = ((bothMask >> k) & 1u) && code == 0;
+        if (p) a1 |= 3u << (2 * k);
+        const bool f = p || code == 3;
+        f1 |= (f ? 1u : 0u) << k;
+        cnt1[k] = f ? 1 : 1 + (int)(nt[k] & 0xFFFFu) + (int)(nt[k] >> 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t code = (a2 >> (2 * q)) & 3u;
+        const bool p = ((f1 >> (2 * q)) & 3u) == 3u && code == 0;
+        if (p) a2 |= 3u << (2 * q);
+        const bool f = p || code == 3;
+        f2 |= (f ? 1u : 0u) << q;
+        cnt2[q] = f ? 1 : 1 + cnt1[2 * q] + cnt1[2 * q + 1];
+    }
+    uint32_t a3 = (c3B >> ((int)(n3 & 3) * 2)) & 15u;           // my two depth-(D-3) codes
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t code = (a3 >> (2 * r)) & 3u;
+        const bool p = ((f2 >> (2 * r)) & 3u) == 3u && code == 0;
+        if (p) a3 |= 3u << (2 * r);
+        const bool f = p || code == 3;
+        f3m |= (f ? 1u : 0u) << r;
+        cnt3[r] = f ? 1 : 1 + cnt2[2 * r] + cnt2[2 * r + 1];
+    }
+    uint32_t a4 = (c4B >> ((int)(n4 & 3) * 2)) & 3u;            // my depth-(D-4) code
+    {
+        const bool p = f3m == 3u && a4 == 0;
+        if (p) a4 = 3u;
+        const bool f = a4 == 3u;
+        flH[256 + t] = (uint8_t)(f ? 1 : 0);
+        cntH[256 + t] = (uint16_t)(f ? 1 : 1 + cnt3[0] + cnt3[1]);
+    }
+    const int cnt4 = a4 == 3u ? 1 : 1 + cnt3[0] + cnt3[1];
+    __syncthreads();
+    // ---- depths D-5 .. D-12 in LDS
+    for (int lq = 7; lq >= 0; --lq) {
+        if (t < (1 << lq)) {
+            const int h = (1 << lq) + t;
+            const uint32_t code = codeH[h];
+            const bool p = flH[2 * h] && flH[2 * h + 1] && code == 0;
+            if (p) codeH[h] = 3;
+            const bool f = p || code == 3;
+            flH[h] = (uint8_t)(f ? 1 : 0);
+            cntH[h] = (uint16_t)(f ? 1u : 1u + cntH[2 * h] + cntH[2 * h + 1]);
+        }
+        __syncthreads();
+    }
+    // the BFS codes are read again only down to depth Ds = D-6 (upper prune levels, k_block_alive, k_concat12's
+    // index values, progressive cuts): write back depths D-12 .. D-5; below that they are dead from here on
+    if (t >= 1 && t < 64) {                               // heap bytes 1..63 <-> heap nodes 4..255 (whole bytes are mine)
+        const int h = t * 4, lq = 31 - __clz(h);
+        const uint8_t pk = (uint8_t)(codeH[h] | (codeH[h + 1] << 2) | (codeH[h + 2] << 4) | (codeH[h + 3] << 6));
+        const uint8_t po = (uint8_t)(codeOldH[h] | (codeOldH[h + 1] << 2) | (codeOldH[h + 2] << 4) | (codeOldH[h + 3] << 6));
+        if (pk != po) Cb[(((int64_t)1 << (D - 12 + lq)) + ((int64_t)blk << lq) + (h - (1 << lq))) >> 2] = pk;
+    }
+    if (t >= 1 && t < 4 && codeH[t] != codeOldH[t]) {     // heap nodes 1..3 share bytes with neighbouring blocks
+        const int lq = 31 - __clz(t);
+        cset3(Cb, ((int64_t)1 << (D - 12 + lq)) + ((int64_t)blk << lq) + (t - (1 << lq)));
+    }
+    if (t == 0) a.subTok[(int64_t)brick * a.nEmitBlk + blk] = cntH[1];
+    // ---- top-down: the block's own token string, root assumed live.  Thread t owns the live nodes whose
+    // first leaf is its first leaf: ancestors at in-block level lq (depth D-12+lq) when t % 2^(8-lq) == 0
+    const int jmin = t ? 8 - (__ffs(t) - 1) : 0;
+    bool alive = true;
+    if (jmin > 0) alive = codeH[(1 << (jmin - 1)) + (t >> (9 - jmin))] != 3;       // parent not pruned
+    uint32_t S = 0;
+    int ns = 0, preDs = 0, aliveAtDs = 0;
+    for (int lq = jmin; lq <= 7 && alive; ++lq) {
+        if (lq == 6) { preDs = ns; aliveAtDs = 1; }
+        const uint32_t code = codeH[(1 << lq) + (t >> (8 - lq))];
+        S |= code << (2 * ns);
+        ++ns;
+        if (code == 3) alive = false;
+    }
+    uint32_t tot;
+    const uint32_t pos = block_excl_scan_u32((uint32_t)(ns + (alive ? cnt4 : 0)), shw, tot);
+    uint32_t bitpos = 2u * pos;
+    pe_put(W, bitpos, (unsigned long long)S, ns);
+    bitpos += 2u * (uint32_t)ns;
+    if (alive) {
+        // preorder of my 31-node subtree; internal tokens wait in (pb, pn) and leave with the next leaf-pair piece
+        unsigned long long pb = a4;
+        int pn = 1;
+        if (a4 != 3u) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t c3 = (a3 >> (2 * r)) & 3u;
+                pb |= (unsigned long long)c3 << (2 * pn); ++pn;
+                if (c3 == 3u) continue;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * r + qq;
+                    const uint32_t c2 = (a2 >> (2 * q)) & 3u;
+                    pb |= (unsigned long long)c2 << (2 * pn); ++pn;
+                    if (c2 == 3u) continue;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const int k = 2 * q + kk;
+                        const uint32_t c1 = (a1 >> (2 * k)) & 3u;
+                        unsigned long long H = c1;
+                        int Hn = 1;
+                        if (c1 != 3u) {
+                            const uint32_t Lb = lcode[k] | (chain[k] << 2);          // per lane: code + grown branch
+                            const int n0 = (int)(nt[k] & 0xFFFFu), n1t = (int)(nt[k] >> 16);
+                            H |= ((unsigned long long)(Lb & 0xFFFFu) << 2) | ((unsigned long long)(Lb >> 16) << (2 + 2 * n0));
+                            Hn = 1 + n0 + n1t;
+                        }
+                        pe_put(W, bitpos, pb | (H << (2 * pn)), pn + Hn);
+                        bitpos += 2u * (uint32_t)(pn + Hn);
+                        pb = 0; pn = 0;
+                    }
+                }
+            }
+        }
+        pe_put(W, bitpos, pb, pn);
+    }
+    if ((t & 3) == 0)       // decode side-car index: the depth-Ds node of every 64 leaves, block-local for now
+        a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + (t >> 2)] = aliveAtDs ? pos + (uint32_t)preDs : VR_IDX_DEAD;
+    __syncthreads();
+    const uint32_t nw = (tot + 15u) >> 4;
+    for (uint32_t i = t; i < nw; i += 256)
+        *pe_stage(a.temp, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk, i) = W[i];
+}
+
+
 __global__ void __launch_bounds__(EMIT_RANKS_PER_BLOCK)
 k_emit_count(EmitArgs a)
 {
@@ -1492,19 +1771,19 @@ __device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const
 // that ancestor's first leaf (the pruned ancestor's own token belongs to the block that does).
 // Lets k_emit4 skip the constant regions of a volume without touching their leaf arrays.
 __global__ void __launch_bounds__(256)
-k_block_alive(EmitArgs a, int64_t nblk)
+k_block_alive(EmitArgs a, int64_t nblk, int sub)     // sub: log2 of the leaves per emit block (10: k_emit4, 12: k_concat12)
 {
     const int brick = blockIdx.y;
     const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blk >= nblk || a.ctrls[brick].constBrick) return;
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     const uint8_t *dmap = a.ctrls[brick].distanceMap;
-    const int dl = a.D - 10;
+    const int dl = a.D - sub;
     bool alive = true;
     int val = dmap[0];                       // decoded scalar along the path (root: R.cpp:743)
     unsigned long long spine = 0;            // tokens above depth D-10 owned by the block's first rank
     int nsp = 0;
-    const uint32_t r0 = (uint32_t)blk << 10;
+    const uint32_t r0 = (uint32_t)blk << sub;
     const int jmin = r0 ? a.D - (__ffs((int)r0) - 1) : 0;     // first spine depth of rank r0 (<= dl)
     bool pathAlive = true;
     for (int j = 0; j < dl; ++j) {
@@ -1615,6 +1894,66 @@ k_emit4(EmitArgs a)
     for (uint32_t i = threadIdx.x; i < nw; i += 256) {
         if (i == 0 || i == nw - 1) { if (W[i]) atomicOr(&G[i], W[i]); }
         else G[i] = W[i];
+    }
+}
+
+// Moves the block strings k_prune_emit12 staged to their final places: block b contributes the upper spine
+// its first rank owns (k_block_alive) and, if its depth-(D-12) root is live, its staged string, at token
+// offset blockOff[b].  Also turns the block-local index offsets into stream offsets and fills the index
+// values (the scalar decoded down to depth Ds; codes under a pruned node are all 3, so the walk is the
+// same for live and dead entries).
+__global__ void __launch_bounds__(256)
+k_concat12(EmitArgs a)
+{
+    const int brick = blockIdx.y, t = threadIdx.x, D = a.D;
+    Ctrl &c = a.ctrls[brick];
+    if (c.constBrick) return;
+    const uint32_t blk = blockIdx.x;
+    const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
+    const int bflags = a.blockAlive[bo];
+    const int bval = a.blockVal[bo];
+    const unsigned long long upSpine = a.blockSpine[bo];
+    const uint32_t g0 = a.blockOff[bo], tot = a.blockTot[bo];
+    const int nsp = (int)(upSpine >> 56);
+    const unsigned long long spine = upSpine & 0x00FFFFFFFFFFFFFFull;
+    if (t < 64) {                                   // the block's 64 index entries (depth Ds = D-6)
+        const uint32_t s = (blk << 6) + (uint32_t)t;
+        const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
+        int val = bval;                             // scalar of the block root's parent
+        for (int j = D - 12; j <= a.Ds; ++j) {
+            const int code = cget(Cb, ((int64_t)1 << j) + (s >> (a.Ds - j)));
+            val = j == 0 ? val : apply_code(val, code, c.distanceMap[j]);
+        }
+        const int64_t io = (int64_t)brick * a.nIdx + s;
+        const uint32_t local = a.idxOff[io];
+        a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? g0 + (uint32_t)nsp + local : VR_IDX_DEAD;
+        a.idxVal[io] = (uint8_t)val;
+    }
+    if (!(bflags & 1) || tot == 0) return;
+    // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
+    // would be a bug; it must surface as a failed parity check, not as a memory fault)
+    if (((unsigned long long)g0 + tot + 32ull) * 2ull > (unsigned long long)a.treeCap * 8ull) {
+        if (t == 0) atomicMax(&c.emitOverflow, 1);
+        return;
+    }
+    const uint32_t cnt = (bflags & 2) ? tot - (uint32_t)nsp : 0u;      // staged tokens
+    const int nws = (int)((cnt + 15u) >> 4);
+    const uint32_t phase = g0 & 15u;
+    const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
+    uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
+    uint8_t *tempW = const_cast<uint8_t *>(a.temp);
+    for (uint32_t i = t; i < nwo; i += 256) {
+        const int bo2 = 2 * (16 * (int)i - (int)phase);                // bit offset of this word in spine ++ staged
+        uint32_t v = 0;
+        if (nsp) v = bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
+        if (cnt) {
+            const int so = bo2 - 2 * nsp, sw = so >> 5, sb = so & 31;  // staged bit offset (floor division)
+            const uint32_t lo = (sw >= 0 && sw < nws) ? *pe_stage(tempW, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk, (uint32_t)sw) : 0u;
+            const uint32_t hi = (sw + 1 >= 0 && sw + 1 < nws) ? *pe_stage(tempW, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk, (uint32_t)(sw + 1)) : 0u;
+            v |= sb ? (lo >> sb) | (hi << (32 - sb)) : lo;
+        }
+        if (i == 0 || i == nwo - 1) { if (v) atomicOr(&G[i], v); }
+        else G[i] = v;
     }
 }
 
@@ -1808,7 +2147,17 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     int pruneFrom = D - 1;
-    if (D >= 12) {
+    const bool fused = !mr && D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
+    if (fused) {
+        PruneEmitArgs pa;
+        pa.D = D; pa.tol = bs->tolerance; pa.maxDepth = bs->maxDepth; pa.ctrls = bs->mid.ctrl;
+        pa.temp = bs->mid.temp; pa.codes = bs->mid.codes;
+        pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->leafStride;
+        pa.rb = rb; pa.subTok = bs->blockOff; pa.nEmitBlk = bs->nEmitBlk; pa.blockL1 = bs->blockL1;
+        pa.chainLut = bs->chainLut; pa.idxOff = bs->idxOff; pa.nIdx = bs->nIdx;
+        hipLaunchKernelGGL(k_prune_emit12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
+        pruneFrom = D - 13;
+    } else if (D >= 12) {
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
                            bs->codeStride, rb, bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
@@ -1841,14 +2190,15 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
     a.chainLut = bs->chainLut;
     const bool quad = !mr && D >= 12 && bs->K >= 2;
-    const int64_t nblk = cdiv((int64_t)1 << D, quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK);
-    if (quad) hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);   // + token counts
+    const int64_t nblk = cdiv((int64_t)1 << D, fused ? 4096 : (quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK));
+    if (quad) hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk, fused ? 12 : 10);   // + token counts
     else hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     dbg_sync(st, "block_alive/count");
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     dbg_sync(st, "emit_scan");
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-    if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    if (fused) hipLaunchKernelGGL(k_concat12, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    else if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     // statistics records: one per 1024 leaves from k_prune12, one per 256 from k_prune_leaf
     hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, (int64_t)(D >= 12 ? cdiv((int64_t)1 << D, 1024) : cdiv((int64_t)1 << D, 256)));
