@@ -1902,30 +1902,42 @@ k_emit4(EmitArgs a)
 // offset blockOff[b].  Also turns the block-local index offsets into stream offsets and fills the index
 // values (the scalar decoded down to depth Ds; codes under a pruned node are all 3, so the walk is the
 // same for live and dead entries).
-__global__ void __launch_bounds__(256)
-k_concat12(EmitArgs a)
+__global__ void __launch_bounds__(64)
+k_concat12(EmitArgs a)       // one wave per block string: many small workgroups in flight hide the memory round trips
 {
     const int brick = blockIdx.y, t = threadIdx.x, D = a.D;
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
     const uint32_t blk = blockIdx.x;
     const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
+    // round trip 1: the block record, my index entry and the seven codes above it (all independent)
     const int bflags = a.blockAlive[bo];
     const int bval = a.blockVal[bo];
     const unsigned long long upSpine = a.blockSpine[bo];
     const uint32_t g0 = a.blockOff[bo], tot = a.blockTot[bo];
+    const uint32_t s = (blk << 6) + (uint32_t)t;                        // my depth-Ds (= D-6) subtree
+    const int64_t io = (int64_t)brick * a.nIdx + s;
+    const uint32_t local = a.idxOff[io];
+    const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
+    uint32_t cb[7];
+    int csh[7], dist[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int j = D - 12 + q;
+        const int64_t ni = ((int64_t)1 << j) + (s >> (6 - q));
+        cb[q] = Cb[ni >> 2];
+        csh[q] = (int)(ni & 3) * 2;
+        dist[q] = c.distanceMap[j];
+    }
     const int nsp = (int)(upSpine >> 56);
     const unsigned long long spine = upSpine & 0x00FFFFFFFFFFFFFFull;
-    if (t < 64) {                                   // the block's 64 index entries (depth Ds = D-6)
-        const uint32_t s = (blk << 6) + (uint32_t)t;
-        const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
+    {
         int val = bval;                             // scalar of the block root's parent
-        for (int j = D - 12; j <= a.Ds; ++j) {
-            const int code = cget(Cb, ((int64_t)1 << j) + (s >> (a.Ds - j)));
-            val = j == 0 ? val : apply_code(val, code, c.distanceMap[j]);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int code = (int)((cb[q] >> csh[q]) & 3u);
+            val = (D - 12 + q) == 0 ? val : apply_code(val, code, dist[q]);
         }
-        const int64_t io = (int64_t)brick * a.nIdx + s;
-        const uint32_t local = a.idxOff[io];
         a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? g0 + (uint32_t)nsp + local : VR_IDX_DEAD;
         a.idxVal[io] = (uint8_t)val;
     }
@@ -1942,18 +1954,28 @@ k_concat12(EmitArgs a)
     const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
     uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
     uint8_t *tempW = const_cast<uint8_t *>(a.temp);
-    for (uint32_t i = t; i < nwo; i += 256) {
-        const int bo2 = 2 * (16 * (int)i - (int)phase);                // bit offset of this word in spine ++ staged
-        uint32_t v = 0;
-        if (nsp) v = bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
-        if (cnt) {
-            const int so = bo2 - 2 * nsp, sw = so >> 5, sb = so & 31;  // staged bit offset (floor division)
-            const uint32_t lo = (sw >= 0 && sw < nws) ? *pe_stage(tempW, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk, (uint32_t)sw) : 0u;
-            const uint32_t hi = (sw + 1 >= 0 && sw + 1 < nws) ? *pe_stage(tempW, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk, (uint32_t)(sw + 1)) : 0u;
-            v |= sb ? (lo >> sb) | (hi << (32 - sb)) : lo;
+    const int ra = c.ra, rbI = c.rb;
+    for (uint32_t i0 = 0; i0 < nwo; i0 += 256) {        // four words per lane and trip: eight loads in flight
+        uint32_t lo[4], hi[4];
+        int sbv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
+            const int so = 2 * (16 * (int)i - (int)phase) - 2 * nsp, sw = so >> 5;     // staged bit offset (floor division)
+            sbv[u] = so & 31;
+            lo[u] = (cnt && i < nwo && sw >= 0 && sw < nws) ? *pe_stage(tempW, a.heapStride, a.rb, ra, rbI, a.leafStride, brick, blk, (uint32_t)sw) : 0u;
+            hi[u] = (cnt && i < nwo && sw + 1 >= 0 && sw + 1 < nws) ? *pe_stage(tempW, a.heapStride, a.rb, ra, rbI, a.leafStride, brick, blk, (uint32_t)(sw + 1)) : 0u;
         }
-        if (i == 0 || i == nwo - 1) { if (v) atomicOr(&G[i], v); }
-        else G[i] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
+            if (i >= nwo) continue;
+            const int bo2 = 2 * (16 * (int)i - (int)phase);            // bit offset of this word in spine ++ staged
+            uint32_t v = sbv[u] ? (lo[u] >> sbv[u]) | (hi[u] << (32 - sbv[u])) : lo[u];
+            if (nsp) v |= bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
+            if (i == 0 || i == nwo - 1) { if (v) atomicOr(&G[i], v); }
+            else G[i] = v;
+        }
     }
 }
 
@@ -2197,7 +2219,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     dbg_sync(st, "emit_scan");
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-    if (fused) hipLaunchKernelGGL(k_concat12, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+    if (fused) hipLaunchKernelGGL(k_concat12, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
     else if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     // statistics records: one per 1024 leaves from k_prune12, one per 256 from k_prune_leaf
