@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned lo
     if (hi) atomicOr(&W[w + 2], hi);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 k_prune_emit12(PruneEmitArgs a)
 {
     __shared__ uint32_t lutS[256];
@@ -1292,7 +1292,7 @@ k_prune_emit12(PruneEmitArgs a)
     // ---- leaves: prune (R.cpp:618-626), grown branches (R.cpp:655-704); sibling leaves share packed 16-bit lanes
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
     const uint32_t tol2 = (uint32_t)tol * 0x10001u;
-    uint32_t T2[8], m[8], sg[8], act[8], nt[8], chain[8], lcode[8];
+    uint32_t T2[8], m[8], sg[8], act[8], nt[8], Lb[8];      // Lb: per lane the leaf's code + its grown branch << 2
     uint32_t bothMask = 0, anyAct = 0;
     vr_s16x2 mxB = (vr_s16x2)(0);
 #pragma unroll
@@ -1309,7 +1309,7 @@ k_prune_emit12(PruneEmitArgs a)
         const uint32_t isz = pk_u((pk_s(cl2) - pk_s(0x00010001u)) >> 15), is3 = pk_u((pk_s(0x00020002u) - pk_s(cl2)) >> 15);
         const uint32_t newp = isz & lt;
         const uint32_t pruned = newp | is3;
-        lcode[j] = cl2 | (newp & 0x00030003u);
+        const uint32_t lcode = cl2 | (newp & 0x00030003u);
         bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
         const vr_s16x2 lim = __builtin_elementwise_min(pk_s(T2[j]), pk_s(T2[j] ^ 0x00FF00FFu));
         const uint32_t viol = pk_u((lim - mm) >> 15);                                          // a clamp could matter
@@ -1317,7 +1317,7 @@ k_prune_emit12(PruneEmitArgs a)
         const uint32_t useL = ~pruned & ~viol;
         const uint32_t ch2 = (e0 & 0x3FFFu) | ((e1 & 0x3FFFu) << 16);
         const uint32_t mir = ch2 ^ (((ch2 ^ (ch2 >> 1)) & 0x15551555u) * 3u);                   // add <-> sub
-        chain[j] = useL & ((sg[j] & mir) | (~sg[j] & ch2));
+        Lb[j] = lcode | ((useL & ((sg[j] & mir) | (~sg[j] & ch2))) << 2);
         nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
         m[j] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[j]);
         act[j] = ~pruned & viol;
@@ -1340,7 +1340,7 @@ k_prune_emit12(PruneEmitArgs a)
             const vr_s16x2 nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
             const uint32_t take = go & pk_u((ax - mm) >> 15);
             const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[j]));                        // add = 1, sub = 2
-            chain[j] |= ((take & dir) | term) << (2 * i);
+            Lb[j] |= ((take & dir) | term) << (2 * i + 2);
             m[j] = (take & pk_u(ax)) | (~take & m[j]);
             sg[j] ^= take & pk_u(nx >> 15);
             act[j] = go;
@@ -1470,9 +1470,8 @@ k_prune_emit12(PruneEmitArgs a)
                         unsigned long long H = c1;
                         int Hn = 1;
                         if (c1 != 3u) {
-                            const uint32_t Lb = lcode[k] | (chain[k] << 2);          // per lane: code + grown branch
                             const int n0 = (int)(nt[k] & 0xFFFFu), n1t = (int)(nt[k] >> 16);
-                            H |= ((unsigned long long)(Lb & 0xFFFFu) << 2) | ((unsigned long long)(Lb >> 16) << (2 + 2 * n0));
+                            H |= ((unsigned long long)(Lb[k] & 0xFFFFu) << 2) | ((unsigned long long)(Lb[k] >> 16) << (2 + 2 * n0));
                             Hn = 1 + n0 + n1t;
                         }
                         pe_put(W, bitpos, pb | (H << (2 * pn)), pn + Hn);
