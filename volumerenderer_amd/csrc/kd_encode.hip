@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned lo
     if (hi) atomicOr(&W[w + 2], hi);
 }
 
-__global__ void __launch_bounds__(256, 5)
+__global__ void __launch_bounds__(256, 6)
 k_prune_emit12(PruneEmitArgs a)
 {
     __shared__ uint32_t lutS[256];
@@ -1292,65 +1292,71 @@ k_prune_emit12(PruneEmitArgs a)
     // ---- leaves: prune (R.cpp:618-626), grown branches (R.cpp:655-704); sibling leaves share packed 16-bit lanes
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
     const uint32_t tol2 = (uint32_t)tol * 0x10001u;
-    uint32_t T2[8], m[8], sg[8], act[8], nt[8], Lb[8];      // Lb: per lane the leaf's code + its grown branch << 2
-    uint32_t bothMask = 0, anyAct = 0;
-    vr_s16x2 mxB = (vr_s16x2)(0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
-        T2[j] = __builtin_amdgcn_perm(0, tw[j >> 1], sel);
-        const vr_s16x2 dl = pk_s(T2[j]) - pk_s(__builtin_amdgcn_perm(0, rw[j >> 1], sel));
-        const vr_s16x2 mm = pk_abs(dl);
-        m[j] = pk_u(mm);
-        sg[j] = pk_u(dl >> 15);
-        mxB = __builtin_elementwise_max(mxB, mm);
-        const uint32_t lt = pk_u((mm - pk_s(tol2)) >> 15);                                     // err < tol
-        const uint32_t cl2 = ((cpk >> (4 * j)) & 3u) | (((cpk >> (4 * j + 2)) & 3u) << 16);     // the pair's codes
-        const uint32_t isz = pk_u((pk_s(cl2) - pk_s(0x00010001u)) >> 15), is3 = pk_u((pk_s(0x00020002u) - pk_s(cl2)) >> 15);
-        const uint32_t newp = isz & lt;
-        const uint32_t pruned = newp | is3;
-        const uint32_t lcode = cl2 | (newp & 0x00030003u);
-        bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
-        const vr_s16x2 lim = __builtin_elementwise_min(pk_s(T2[j]), pk_s(T2[j] ^ 0x00FF00FFu));
-        const uint32_t viol = pk_u((lim - mm) >> 15);                                          // a clamp could matter
-        const uint32_t e0 = lutS[m[j] & 255u], e1 = lutS[(m[j] >> 16) & 255u];
-        const uint32_t useL = ~pruned & ~viol;
-        const uint32_t ch2 = (e0 & 0x3FFFu) | ((e1 & 0x3FFFu) << 16);
-        const uint32_t mir = ch2 ^ (((ch2 ^ (ch2 >> 1)) & 0x15551555u) * 3u);                   // add <-> sub
-        Lb[j] = lcode | ((useL & ((sg[j] & mir) | (~sg[j] & ch2))) << 2);
-        nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
-        m[j] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[j]);
-        act[j] = ~pruned & viol;
-        anyAct |= act[j];
-    }
+    uint32_t nt[8], Lb[8];      // per lane: tokens the leaf emits when live; its code + grown branch << 2
+    uint32_t bothMask = 0;
+    vr_s16x2 mxB = (vr_s16x2)(0), mxA = (vr_s16x2)(0), l1p = (vr_s16x2)(0);
     const int nsteps = a.maxDepth - D;    // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
-    for (int i = 0; i < nsteps; ++i) {    // exact stepping for the leaves the table does not cover
-        if (__ballot(anyAct != 0) == 0ull) break;
-        const uint32_t d2 = (uint32_t)(64 >> i) * 0x10001u;
-        anyAct = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const vr_s16x2 mm = pk_s(m[j]);
-            const uint32_t gt = pk_u((pk_s(tol2) - mm) >> 15);
-            nt[j] = pk_u(pk_s(nt[j]) - pk_s(act[j]));
-            const uint32_t go = act[j] & gt;
-            const uint32_t term = (act[j] ^ go) & 0x00030003u;                                 // R.cpp:699-703
-            const uint32_t lim = (sg[j] & T2[j]) | (~sg[j] & (T2[j] ^ 0x00FF00FFu));
-            const vr_s16x2 x = __builtin_elementwise_min(pk_s(d2) - mm, pk_s(lim));
-            const vr_s16x2 nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
-            const uint32_t take = go & pk_u((ax - mm) >> 15);
-            const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[j]));                        // add = 1, sub = 2
-            Lb[j] |= ((take & dir) | term) << (2 * i + 2);
-            m[j] = (take & pk_u(ax)) | (~take & m[j]);
-            sg[j] ^= take & pk_u(nx >> 15);
-            act[j] = go;
-            anyAct |= go;
+    for (int half = 0; half < 2; ++half) {          // two halves of four sibling pairs: halves the transient registers
+        uint32_t T2[4], m[4], sg[4], act[4];
+        uint32_t anyAct = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = half * 4 + jj;
+            const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
+            T2[jj] = __builtin_amdgcn_perm(0, tw[j >> 1], sel);
+            const vr_s16x2 dl = pk_s(T2[jj]) - pk_s(__builtin_amdgcn_perm(0, rw[j >> 1], sel));
+            const vr_s16x2 mm = pk_abs(dl);
+            m[jj] = pk_u(mm);
+            sg[jj] = pk_u(dl >> 15);
+            mxB = __builtin_elementwise_max(mxB, mm);
+            const uint32_t lt = pk_u((mm - pk_s(tol2)) >> 15);                                     // err < tol
+            const uint32_t cl2 = ((cpk >> (4 * j)) & 3u) | (((cpk >> (4 * j + 2)) & 3u) << 16);     // the pair's codes
+            const uint32_t isz = pk_u((pk_s(cl2) - pk_s(0x00010001u)) >> 15), is3 = pk_u((pk_s(0x00020002u) - pk_s(cl2)) >> 15);
+            const uint32_t newp = isz & lt;
+            const uint32_t pruned = newp | is3;
+            const uint32_t lcode = cl2 | (newp & 0x00030003u);
+            bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
+            const vr_s16x2 lim = __builtin_elementwise_min(pk_s(T2[jj]), pk_s(T2[jj] ^ 0x00FF00FFu));
+            const uint32_t viol = pk_u((lim - mm) >> 15);                                          // a clamp could matter
+            const uint32_t e0 = lutS[m[jj] & 255u], e1 = lutS[(m[jj] >> 16) & 255u];
+            const uint32_t useL = ~pruned & ~viol;
+            const uint32_t ch2 = (e0 & 0x3FFFu) | ((e1 & 0x3FFFu) << 16);
+            const uint32_t mir = ch2 ^ (((ch2 ^ (ch2 >> 1)) & 0x15551555u) * 3u);                   // add <-> sub
+            Lb[j] = lcode | ((useL & ((sg[jj] & mir) | (~sg[jj] & ch2))) << 2);
+            nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
+            m[jj] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[jj]);
+            act[jj] = ~pruned & viol;
+            anyAct |= act[jj];
         }
+        for (int i = 0; i < nsteps; ++i) {    // exact stepping for the leaves the table does not cover
+            if (__ballot(anyAct != 0) == 0ull) break;
+            const uint32_t d2 = (uint32_t)(64 >> i) * 0x10001u;
+            anyAct = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = half * 4 + jj;
+                const vr_s16x2 mm = pk_s(m[jj]);
+                const uint32_t gt = pk_u((pk_s(tol2) - mm) >> 15);
+                nt[j] = pk_u(pk_s(nt[j]) - pk_s(act[jj]));
+                const uint32_t go = act[jj] & gt;
+                const uint32_t term = (act[jj] ^ go) & 0x00030003u;                                 // R.cpp:699-703
+                const uint32_t lim = (sg[jj] & T2[jj]) | (~sg[jj] & (T2[jj] ^ 0x00FF00FFu));
+                const vr_s16x2 x = __builtin_elementwise_min(pk_s(d2) - mm, pk_s(lim));
+                const vr_s16x2 nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
+                const uint32_t take = go & pk_u((ax - mm) >> 15);
+                const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[jj]));                        // add = 1, sub = 2
+                Lb[j] |= ((take & dir) | term) << (2 * i + 2);
+                m[jj] = (take & pk_u(ax)) | (~take & m[jj]);
+                sg[jj] ^= take & pk_u(nx >> 15);
+                act[jj] = go;
+                anyAct |= go;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { mxA = __builtin_elementwise_max(mxA, pk_s(m[jj])); l1p += pk_s(m[jj]); }
     }
     {   // statistics (R.cpp:71-76, 115-129): one record per wave = 1024 leaves
-        vr_s16x2 mxA = (vr_s16x2)(0), l1p = (vr_s16x2)(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { mxA = __builtin_elementwise_max(mxA, pk_s(m[j])); l1p += pk_s(m[j]); }
         int maxErr = max((int)mxB.x, (int)mxB.y), maxAfter = max((int)mxA.x, (int)mxA.y);
         unsigned long long l1w = (unsigned long long)((int)l1p.x + (int)l1p.y);
         for (int o = 32; o > 0; o >>= 1) {
