@@ -257,3 +257,21 @@ def test_progressive_cut_matches_oracle(vr, oracle, tmp_path):
                 continue
             got = fs.decode(cut_depth=cut).cpu().numpy().reshape(z, y, x)
             assert np.array_equal(got, ref.levelCutProgressive(cut)), "foreign cut %d" % cut
+
+
+def test_fused_emit_equals_two_pass_emit(vr, oracle, monkeypatch):
+    """The default D >= 12 path (k_prune_emit12 + k_concat12) and the older per-quad emitter kept behind
+    VRHIP_NO_FUSED_EMIT must produce the same bytes, index and statistics."""
+    rng = np.random.default_rng(21)
+    vols = [rm_like((32, 64, 32)), rng.integers(0, 256, (32, 64, 32), dtype=np.uint8), oracle.gen_sphere(32, 3).repeat(2, axis=1)]
+    res = []
+    for env in (None, "1"):
+        if env: monkeypatch.setenv("VRHIP_NO_FUSED_EMIT", env)
+        bs = vr.BrickSet(len(vols), (32, 64, 32), 1, 2)
+        bs.build(np.stack(vols))
+        dec = bs.decode().cpu().numpy()
+        res.append([(bs.tree(i).tobytes(), tuple(sorted(bs.info(i).items()))) for i in range(len(vols))] + [dec.tobytes()])
+    monkeypatch.delenv("VRHIP_NO_FUSED_EMIT")
+    assert res[0] == res[1]
+    ref = oracle.OracleTree(vols[1].copy(), tolerance=1, max_epochs=2).build()
+    assert res[0][1][0] == ref.tree.tobytes()
