@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="2 (default): two bricksets on two HIP streams, levelCut of step k overlaps build of step k+1 "
+                         "(the streaming use: the next timestep compresses while this one decodes); 1: strictly serial")
     ap.add_argument("--composite", action="store_true",
                     help="N > 1 only: also time a sort-last composited 1080p frame over RCCL (off by default: a "
                          "collective that fails on one rank must never hang the headline measurement)")
@@ -151,20 +154,37 @@ def main():
     vox = vox4.reshape(-1)                                      # inputs resident in HBM before timing
     out = torch.empty_like(vox)
     bs = vr.BrickSet(B, bdims, args.tolerance, args.max_epochs)
+    sets = [bs] + [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(args.pipeline - 1)]
+    s_build, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
 
-    def step():
-        bs.build(vox)
-        bs.decode(out)
+    def run_steps(n):
+        """n x (build + levelCut) of the whole volume; every launch of every step is inside the caller's timed
+        region.  pipeline == 2: brickset k%2 is built on one stream and decoded on the other, so the decode of
+        step k runs beside the build of step k+1; a brickset is rebuilt only after its decode has finished."""
+        if args.pipeline == 1:
+            for _ in range(n):
+                bs.build(vox)
+                bs.decode(out)
+            return
+        built = [None] * len(sets)
+        decoded = [None] * len(sets)
+        for k in range(n):
+            i = k % len(sets)
+            if decoded[i] is not None:
+                s_build.wait_event(decoded[i])
+            sets[i].build(vox, stream=s_build)
+            built[i] = torch.cuda.Event(); built[i].record(s_build)
+            s_dec.wait_event(built[i])
+            sets[i].decode(out, stream=s_dec)
+            decoded[i] = torch.cuda.Event(); decoded[i].record(s_dec)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,11 +197,13 @@ def main():
     total_vox = float(V) * B * world * args.steps
     value = total_vox / dt / 1e6
 
-    # per-kernel timing outside the timed region: hipEvents on the launch stream (vr_brickset_last_timings)
+    # per-kernel timing outside the timed region, strictly serial: hipEvents on the launch stream
+    # (vr_brickset_last_timings)
     enc_ms, dec_ms = [], []
     for _ in range(3):
         bs.build(vox)
         bs.decode(out)
+        torch.cuda.synchronize()
         tm = bs.last_timings()
         enc_ms.append(tm["BUILD"] + tm["COMPRESS"] + tm["PRUNE"] + tm["CONVERT"])
         dec_ms.append(tm["DECODE"])
@@ -219,9 +241,12 @@ def main():
                       "maxEpochs %d, VolumeKdtree build + levelCut" % (gdims[0], gdims[1], gdims[2], B, bdims[0],
                                                                          bdims[1], bdims[2], args.kind, args.tolerance,
                                                                          args.max_epochs),
+                      "pipeline": ("levelCut of step k overlaps build of step k+1 (2 bricksets, 2 HIP streams)"
+                                   if args.pipeline == 2 else "serial"),
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
+           "serial_ms_per_step": round(sum(enc_ms) / len(enc_ms) + dec_avg_s * 1e3, 3),
            "encode_ms": round(sum(enc_ms) / len(enc_ms), 3), "decode_ms": round(dec_avg_s * 1e3, 3),
            "phases_ms": {k: round(v, 3) for k, v in phases.items()},
            "roofline": roofline}
