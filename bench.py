@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--groups", type=int, default=1, help="pipeline 2: independent brick groups (streams) per step")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
                     help="2 (default): two bricksets on two HIP streams, levelCut of step k overlaps build of step k+1 "
                          "(the streaming use: the next timestep compresses while this one decodes); 1: strictly serial")
@@ -132,9 +133,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # VRHIP_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box (every rank on device 0, gloo)
+    rehearsal = os.environ.get("VRHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import volumerenderer_amd as vr
 
@@ -154,8 +162,17 @@ def main():
     vox = vox4.reshape(-1)                                      # inputs resident in HBM before timing
     out = torch.empty_like(vox)
     bs = vr.BrickSet(B, bdims, args.tolerance, args.max_epochs)
-    sets = [bs] + [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(args.pipeline - 1)]
-    s_build, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+    # pipeline == 2: the bricks are dealt to `groups` independent brickset pairs, each with its own build and
+    # decode stream, so one group's serial per-level kernels (one wave per brick) run beside another group's
+    # bandwidth-bound ones and every decode runs beside later builds
+    G = max(1, min(args.groups, B)) if args.pipeline == 2 else 1
+    cuts = [B * g // G for g in range(G + 1)]
+    gsets = [[vr.BrickSet(cuts[g + 1] - cuts[g], bdims, args.tolerance, args.max_epochs) for _ in range(2)]
+             for g in range(G)] if args.pipeline == 2 else []
+    gvox = [vox[cuts[g] * V:cuts[g + 1] * V] for g in range(G)]
+    gout = [out[cuts[g] * V:cuts[g + 1] * V] for g in range(G)]
+    s_build = [torch.cuda.Stream() for _ in range(G)]
+    s_dec = [torch.cuda.Stream() for _ in range(G)]
 
     def run_steps(n):
         """n x (build + levelCut) of the whole volume; every launch of every step is inside the caller's timed
@@ -166,17 +183,17 @@ def main():
                 bs.build(vox)
                 bs.decode(out)
             return
-        built = [None] * len(sets)
-        decoded = [None] * len(sets)
+        decoded = [[None, None] for _ in range(G)]
         for k in range(n):
-            i = k % len(sets)
-            if decoded[i] is not None:
-                s_build.wait_event(decoded[i])
-            sets[i].build(vox, stream=s_build)
-            built[i] = torch.cuda.Event(); built[i].record(s_build)
-            s_dec.wait_event(built[i])
-            sets[i].decode(out, stream=s_dec)
-            decoded[i] = torch.cuda.Event(); decoded[i].record(s_dec)
+            i = k % 2
+            for g in range(G):
+                if decoded[g][i] is not None:
+                    s_build[g].wait_event(decoded[g][i])
+                gsets[g][i].build(gvox[g], stream=s_build[g])
+                built = torch.cuda.Event(); built.record(s_build[g])
+                s_dec[g].wait_event(built)
+                gsets[g][i].decode(gout[g], stream=s_dec[g])
+                decoded[g][i] = torch.cuda.Event(); decoded[g][i].record(s_dec[g])
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
@@ -191,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_vox = float(V) * B * world * args.steps
@@ -241,8 +258,9 @@ def main():
                       "maxEpochs %d, VolumeKdtree build + levelCut" % (gdims[0], gdims[1], gdims[2], B, bdims[0],
                                                                          bdims[1], bdims[2], args.kind, args.tolerance,
                                                                          args.max_epochs),
-                      "pipeline": ("levelCut of step k overlaps build of step k+1 (2 bricksets, 2 HIP streams)"
-                                   if args.pipeline == 2 else "serial"),
+                      "pipeline": ("%d brick groups x 2 bricksets on %d HIP streams: levelCut of step k overlaps build of "
+                                   "step k+1, one group's serial per-level kernels overlap another's bulk ones"
+                                   % (G, 2 * G) if args.pipeline == 2 else "serial"),
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
