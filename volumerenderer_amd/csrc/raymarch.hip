@@ -39,8 +39,16 @@ __device__ __forceinline__ float tex3d(const Tex &t, float px, float py, float p
     const int64_t sy = t.X, sz = (int64_t)t.X * t.Y;
     const uint8_t *r0 = t.v + sy * ya + sz * za, *r1 = t.v + sy * yb + sz * za;
     const uint8_t *r2 = t.v + sy * ya + sz * zb, *r3 = t.v + sy * yb + sz * zb;
-    float c000 = (float)r0[xa] * k, c100 = (float)r0[xb] * k, c010 = (float)r1[xa] * k, c110 = (float)r1[xb] * k;
-    float c001 = (float)r2[xa] * k, c101 = (float)r2[xb] * k, c011 = (float)r3[xa] * k, c111 = (float)r3[xb] * k;
+    // the two x taps of a row are neighbouring bytes except at a clamped edge: one (unaligned) 16-bit load
+    // per row instead of two byte loads; at an edge both taps are the same voxel
+    typedef uint16_t __attribute__((aligned(1))) u16u;
+    const bool pairx = xb == xa + 1;
+    const int xl = pairx ? xa : (xa < xb ? xa : xb);
+    uint32_t q0, q1, q2, q3;
+    if (pairx) { q0 = *(const u16u *)(r0 + xl); q1 = *(const u16u *)(r1 + xl); q2 = *(const u16u *)(r2 + xl); q3 = *(const u16u *)(r3 + xl); }
+    else { q0 = r0[xa] | (r0[xb] << 8); q1 = r1[xa] | (r1[xb] << 8); q2 = r2[xa] | (r2[xb] << 8); q3 = r3[xa] | (r3[xb] << 8); }
+    float c000 = (float)(q0 & 255u) * k, c100 = (float)(q0 >> 8) * k, c010 = (float)(q1 & 255u) * k, c110 = (float)(q1 >> 8) * k;
+    float c001 = (float)(q2 & 255u) * k, c101 = (float)(q2 >> 8) * k, c011 = (float)(q3 & 255u) * k, c111 = (float)(q3 >> 8) * k;
     float c00 = c000 + fx * (c100 - c000), c10 = c010 + fx * (c110 - c010);
     float c01 = c001 + fx * (c101 - c001), c11 = c011 + fx * (c111 - c011);
     float c0 = c00 + fy * (c10 - c00), c1 = c01 + fy * (c11 - c01);
