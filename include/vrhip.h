@@ -135,6 +135,12 @@ vr_status vr_brickset_set_tree(vr_brickset *bs, int32_t brick, const uint8_t *tr
  * tree bytes.  vr_brickset_open creates a 1-brick set. */
 vr_status vr_brickset_save(vr_brickset *bs, int32_t brick, const char *path);
 vr_status vr_brickset_open(vr_brickset **out, const char *path);
+/* MidRangeTree::save / open (MidRangeTree.cpp:753-833).  A VR_VARIANT_MIDRANGE set saves the
+ * reference's MidRangeTree layout byte for byte: the same 88-byte header, distanceMap,
+ * distanceMap_range, tree bytes, tree_range bytes.  vr_brickset_open_variant(…, VR_VARIANT_MIDRANGE)
+ * reads such a file back exactly (the reference's reader mis-sizes the streams by 4 bytes and returns
+ * a shifted range stream: nothing to match); other variants forward to vr_brickset_open. */
+vr_status vr_brickset_open_variant(vr_brickset **out, const char *path, int32_t variant);
 
 /* ---- error helpers: measureMaxError / measureMeanError / queryError (R.cpp:386-411)
  * The reference dereferences the input it has already cleared (SURVEY C-7); here the

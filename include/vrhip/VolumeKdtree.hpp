@@ -176,6 +176,19 @@ public:
         distanceMap_range.resize((size_t)maxTreeDepth + 1);
         check(vr_brickset_get_distance_map_range(bs, 0, distanceMap_range.data(), maxTreeDepth + 1), "get_distance_map_range");
     }
+    void open(std::string filename)            // M.cpp:787-833 (reads back exactly what save() wrote, see vrhip.h)
+    {
+        using namespace vrhip_detail;
+        vr_brickset_destroy(bs);
+        bs = nullptr;
+        check(vr_brickset_open_variant(&bs, filename.c_str(), VR_VARIANT_MIDRANGE), "vr_brickset_open_variant");
+        refresh();
+        tree_range.bits.resize(tree.bits.size());
+        check(vr_brickset_get_tree_range(bs, 0, tree_range.bits.data(), (int64_t)tree_range.bits.size()), "get_tree_range");
+        distanceMap_range.resize((size_t)maxTreeDepth + 1);
+        check(vr_brickset_get_distance_map_range(bs, 0, distanceMap_range.data(), maxTreeDepth + 1), "get_distance_map_range");
+    }
+    // save(): VolumeKdtree::save on a VR_VARIANT_MIDRANGE set writes MidRangeTree's layout (M.cpp:753-785)
     void convertToByteArray(std::vector<byte> &byteArray)      // M.cpp:1095-1128
     {
         using namespace vrhip_detail;

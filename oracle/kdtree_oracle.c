@@ -668,9 +668,60 @@ int vko_save(const vko_tree *t, const char *filename)
     fwrite(&t->X, 8, 1, f); fwrite(&t->Y, 8, 1, f); fwrite(&t->Z, 8, 1, f);
     fwrite(&t->numActiveNodes, 8, 1, f);
     fwrite(t->distanceMap, 1, (size_t)(t->maxTreeDepth + 1), f);
+    if (t->midrange) {   /* MidRangeTree::save, M.cpp:753-785: both maps, then both streams */
+        fwrite(t->distanceMapRange, 1, (size_t)(t->maxTreeDepth + 1), f);
+        fwrite(t->tree, 1, (size_t)t->treeBytes, f);
+        fwrite(t->treeRange, 1, (size_t)t->treeBytes, f);
+        fclose(f);
+        return 0;
+    }
     fwrite(t->tree, 1, (size_t)t->treeBytes, f);
     fclose(f);
     return 0;
+}
+
+/* MidRangeTree::open, M.cpp:787-833, restated literally.  The size computation subtracts three of
+ * the four int64 fields (:815, like R.cpp:581) and halves: treeSize comes out 4 bytes too large, so
+ * `tree` swallows the first 4 bytes of the range stream and `tree_range` starts 4 bytes late and comes up
+ * 8 bytes short (zero here).  The mid stream still decodes (numActiveNodes bounds the walk); the range
+ * stream read back this way is NOT what was saved.  Test infrastructure documents this; the product's
+ * reader (vr_brickset_open_variant) reads what save() wrote. */
+vko_tree *vko_open_midrange(const char *filename)
+{
+    FILE *f = fopen(filename, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    int64_t fileSize = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    vko_tree *t = (vko_tree *)calloc(1, sizeof(vko_tree));
+    t->tolerance = 6; t->maxEpochs = 5; t->midrange = 1;
+    int32_t mtd = 0, otd = 0;
+    size_t ok = 0;
+    ok += fread(t->rootMin, 8, 3, f);
+    ok += fread(t->rootMax, 8, 3, f);
+    ok += fread(&mtd, 4, 1, f);
+    ok += fread(&otd, 4, 1, f);
+    ok += fread(&t->X, 8, 1, f); ok += fread(&t->Y, 8, 1, f); ok += fread(&t->Z, 8, 1, f);
+    ok += fread(&t->numActiveNodes, 8, 1, f);
+    if (ok != 12 || mtd < 0 || mtd > 255) { fclose(f); free(t); return NULL; }
+    t->maxTreeDepth = mtd; t->origTreeDepth = otd;
+    int64_t treeSize = fileSize - (2 * 24 + 2 * 4 + 2 * (mtd + 1) + 3 * 8); /* sic */
+    treeSize /= 2;
+    if (treeSize < 0) { fclose(f); free(t); return NULL; }
+    t->distanceMapLen = mtd + 1;
+    t->distanceMap = (byte *)calloc((size_t)t->distanceMapLen, 1);
+    t->distanceMapRange = (byte *)calloc((size_t)t->distanceMapLen, 1);
+    t->tree = (byte *)calloc((size_t)treeSize + 1, 1);
+    t->treeRange = (byte *)calloc((size_t)treeSize + 1, 1);
+    t->treeBytes = treeSize; t->treeRangeBytes = treeSize;
+    ok = fread(t->distanceMap, 1, (size_t)(mtd + 1), f);
+    ok = fread(t->distanceMapRange, 1, (size_t)(mtd + 1), f);
+    ok = fread(t->tree, 1, (size_t)treeSize, f);
+    ok = fread(t->treeRange, 1, (size_t)treeSize, f);   /* short read */
+    (void)ok;
+    fclose(f);
+    t->stage = 4;
+    return t;
 }
 
 /* R.cpp:554-594 incl. the 8-byte over-allocation of tree.bits (C-6). */

@@ -82,6 +82,8 @@ def lib():
     L.vko_save.argtypes = [p, C.c_char_p]
     L.vko_open.argtypes = [C.c_char_p]
     L.vko_open.restype = p
+    L.vko_open_midrange.argtypes = [C.c_char_p]
+    L.vko_open_midrange.restype = p
     for name in ("vko_orig_tree_depth", "vko_max_tree_depth", "vko_num_reverts", "vko_zero_run_rewrites",
                  "vko_trace_len"):
         getattr(L, name).argtypes = [p]
@@ -171,6 +173,14 @@ class OracleTree:
     @classmethod
     def open(cls, path):
         h = lib().vko_open(os.fsencode(path))
+        if not h:
+            raise FileNotFoundError(path)
+        return cls(_handle=h)
+
+    @classmethod
+    def open_midrange(cls, path):
+        """MidRangeTree::open restated literally (M.cpp:787-833), defect included: see kdtree_oracle.c."""
+        h = lib().vko_open_midrange(os.fsencode(path))
         if not h:
             raise FileNotFoundError(path)
         return cls(_handle=h)

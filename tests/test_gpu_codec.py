@@ -1,6 +1,8 @@
 """GPU parity: the HIP encode / decode path (through the C ABI) against the CPU oracle.
 
 Bit-exact: tree bytes, distanceMap, numActiveNodes, decoded voxels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -275,3 +277,29 @@ def test_fused_emit_equals_two_pass_emit(vr, oracle, monkeypatch):
     assert res[0] == res[1]
     ref = oracle.OracleTree(vols[1].copy(), tolerance=1, max_epochs=2).build()
     assert res[0][1][0] == ref.tree.tobytes()
+
+
+def test_midrange_file_roundtrip(vr, oracle, tmp_path):
+    """MidRangeTree::save layout byte-identical to the oracle's restatement of M.cpp:753-785; open() returns
+    exactly what was saved (the reference's own reader does not, see test_midrange_file_layout)."""
+    vol = oracle.gen_sphere(32, 7)
+    ref = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=1, midrange=True, guarded=True).build()
+    t = vr.MidRangeTree(vol.copy(), 32, 32, 32)
+    t.setMaxEpochs(1); t.setErrorTolerance(1)
+    t.build()
+    p, q = str(tmp_path / "gpu.bin"), str(tmp_path / "ref.bin")
+    t.save(p); ref.save(q)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    u = vr.MidRangeTree().open(q)
+    assert u.numActiveNodes == ref.numActiveNodes and (u.X, u.Y, u.Z) == (32, 32, 32)
+    assert np.array_equal(u.tree, ref.tree) and np.array_equal(u.tree_range, ref.tree_range)
+    assert list(u.distanceMap) == list(ref.distanceMap) and list(u.distanceMap_range) == list(ref.distanceMap_range)
+    assert np.array_equal(u.convertToByteArray(), ref.convertToByteArray())
+    assert np.array_equal(u.levelCut().cpu().numpy().reshape(32, 32, 32), ref.levelCut())
+    r = str(tmp_path / "again.bin")
+    u.save(r)
+    assert open(r, "rb").read() == open(q, "rb").read()
+    with pytest.raises(vr.VrError):
+        vr.MidRangeTree().open(str(tmp_path / "missing.bin"))
+    with pytest.raises(vr.VrError):
+        vr.MidRangeTree().open(os.path.join(os.path.dirname(__file__), "golden", "ref_sphere_n3_16_tol1_ep2.tree.bin"))

@@ -119,3 +119,22 @@ def test_encode_node_closed_form_exhaustive():
     assert np.array_equal(m, np.minimum(pd, np.abs(x)))
     assert np.array_equal(code, np.where(take, np.where(up, 1, 2), 0))
     assert np.array_equal(recon, np.where(take, np.where(up, t + x, t - x), p + 0 * d))
+
+
+def test_midrange_file_layout(oracle, tmp_path):
+    """MidRangeTree::save (M.cpp:753-785): 88-byte header, both distance maps, both streams; and the
+    reference reader's defect (M.cpp:815: three of four int64 fields subtracted, then halved)."""
+    vol = oracle.gen_sphere(16, 7)
+    t = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=1, midrange=True, guarded=True).build()
+    p = str(tmp_path / "mr.bin")
+    t.save(p)
+    raw = open(p, "rb").read()
+    T, m = len(t.tree), t.maxTreeDepth + 1
+    assert len(raw) == 88 + 2 * m + 2 * T
+    assert raw[88:88 + m] == bytes(t.distanceMap) and raw[88 + m:88 + 2 * m] == bytes(t.distanceMap_range)
+    assert raw[88 + 2 * m:88 + 2 * m + T] == t.tree.tobytes() and raw[88 + 2 * m + T:] == t.tree_range.tobytes()
+    r = oracle.OracleTree.open_midrange(p)
+    assert len(r.tree) == T + 4                                       # over-sized by 8 / 2
+    assert r.tree[:T].tobytes() == t.tree.tobytes()                   # the mid stream survives ...
+    assert r.tree[T:].tobytes() == t.tree_range[:4].tobytes()         # ... followed by the range stream's head
+    assert r.tree_range[:T - 4].tobytes() == t.tree_range[4:].tobytes()   # and the range stream comes back shifted

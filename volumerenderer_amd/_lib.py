@@ -69,6 +69,7 @@ SIGNATURES = {
     "vr_brickset_set_tree": (_I32, [_P, _I32, _P, _I64, _I64, _P, _I32]),
     "vr_brickset_save": (_I32, [_P, _I32, C.c_char_p]),
     "vr_brickset_open": (_I32, [C.POINTER(_P), C.c_char_p]),
+    "vr_brickset_open_variant": (_I32, [C.POINTER(_P), C.c_char_p, _I32]),
     "vr_measure_error": (_I32, [_P, _P, _I64, C.POINTER(_I32), C.POINTER(C.c_double), _P]),
     "vr_query_error": (_I32, [_P, _P, _I64, _P, _P]),
     "vr_assemble_bricks": (_I32, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _P, _P]),

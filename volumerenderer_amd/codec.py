@@ -128,10 +128,10 @@ class BrickSet:
         check(self._L.vr_brickset_save(self._h, int(brick), os.fsencode(path)), "vr_brickset_save")
 
     @classmethod
-    def open(cls, path):
+    def open(cls, path, variant=_lib.VARIANT_RECOVER):
         L = _lib.lib()
         h = C.c_void_p()
-        check(L.vr_brickset_open(C.byref(h), os.fsencode(path)), "vr_brickset_open")
+        check(L.vr_brickset_open_variant(C.byref(h), os.fsencode(path), int(variant)), "vr_brickset_open")
         ti = _lib.TreeInfo()
         check(L.vr_brickset_info(h, 0, C.byref(ti)), "vr_brickset_info")
         return cls(1, (ti.X, ti.Y, ti.Z), _handle=h)
@@ -223,8 +223,8 @@ class VolumeKdtree:
     def save(self, filename):                      # R.cpp:521-552
         self._need().save(filename, 0)
 
-    def open(self, filename):                      # R.cpp:554-594
-        self._bs = BrickSet.open(filename)
+    def open(self, filename):                      # R.cpp:554-594 / M.cpp:787-833
+        self._bs = BrickSet.open(filename, self._variant)
         self.X, self.Y, self.Z = self._bs.dims
         return self
 

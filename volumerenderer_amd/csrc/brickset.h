@@ -44,6 +44,7 @@ struct BrickSet {
     uint8_t *idxValCut = nullptr; // B * nIdx  progressive cut above the index level: ancestor scalars
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
+    bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream
     uint32_t *spread = nullptr;  // rank bits of every x, y, z coordinate: rank(x,y,z) = spread[x] | spread[X+y] | spread[X+Y+z]
 
     std::vector<Ctrl> hostCtrl; // copied back lazily

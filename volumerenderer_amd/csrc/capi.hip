@@ -128,8 +128,8 @@ static vr_status ensure_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.mid.codes, B * (size_t)b.codeStride));
     for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.mid.recon[i], B * (size_t)b.leafStride));
     if (b.variant == VR_VARIANT_MIDRANGE) {
-        HIPCHK(hipMalloc(&b.rng.ctrl, B * sizeof(Ctrl)));
-        HIPCHK(hipMalloc(&b.rng.tree, B * (size_t)b.treeCap));
+        if (!b.rng.ctrl) HIPCHK(hipMalloc(&b.rng.ctrl, B * sizeof(Ctrl)));       // (an opened MidRangeTree file has these already)
+        if (!b.rng.tree) HIPCHK(hipMalloc(&b.rng.tree, B * (size_t)b.treeCap));
         HIPCHK(hipMalloc(&b.rng.temp, B * (size_t)b.heapStride));
         HIPCHK(hipMalloc(&b.rng.codes, B * (size_t)b.codeStride));
         for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.rng.recon[i], B * (size_t)b.leafStride));
@@ -326,7 +326,7 @@ vr_status vr_brickset_get_distance_map(vr_brickset *h, int32_t brick, uint8_t *d
 vr_status vr_brickset_get_tree_range(vr_brickset *h, int32_t brick, uint8_t *dst, int64_t cap)
 {
     if (!h || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
-    if (h->s.variant != VR_VARIANT_MIDRANGE || h->s.foreign) return VR_ERR_STATE;
+    if (h->s.variant != VR_VARIANT_MIDRANGE || (h->s.foreign && !h->s.foreignRange)) return VR_ERR_STATE;
     return get_tree_common(h->s, h->s.rng, brick, dst, cap);
 }
 
@@ -334,7 +334,7 @@ vr_status vr_brickset_get_distance_map_range(vr_brickset *h, int32_t brick, uint
 {
     if (!h || !dst || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
     BrickSet &b = h->s;
-    if (b.variant != VR_VARIANT_MIDRANGE || b.foreign) return VR_ERR_STATE;
+    if (b.variant != VR_VARIANT_MIDRANGE || (b.foreign && !b.foreignRange)) return VR_ERR_STATE;
     vr_status rc = sync_ctrl(b);
     if (rc != VR_OK) return rc;
     if (cap < b.maxDepth + 1) return VR_ERR_INVALID;
@@ -351,7 +351,7 @@ vr_status vr_brickset_get_packed4(vr_brickset *h, int32_t brick, uint8_t *dst, i
 {
     if (!h || !length || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
     BrickSet &b = h->s;
-    if (b.variant != VR_VARIANT_MIDRANGE || b.foreign) return VR_ERR_STATE;
+    if (b.variant != VR_VARIANT_MIDRANGE || (b.foreign && !b.foreignRange)) return VR_ERR_STATE;
     vr_status rc = sync_ctrl(b);
     if (rc != VR_OK) return rc;
     const int64_t n = (int64_t)b.hostCtrl[brick].numActive;
@@ -451,6 +451,16 @@ vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
     if (bytes == 0) return VR_ERR_STATE;
     std::vector<uint8_t> tree((size_t)bytes);
     HIPCHK(hipMemcpy(tree.data(), b.mid.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    // MidRangeTree::save (M.cpp:753-785): same header, then distanceMap, distanceMap_range, tree, tree_range
+    const bool mrFile = b.variant == VR_VARIANT_MIDRANGE;
+    std::vector<uint8_t> treeR;
+    Ctrl cr;
+    if (mrFile) {
+        if (b.foreign && !b.foreignRange) return VR_ERR_STATE;
+        treeR.resize((size_t)bytes);
+        HIPCHK(hipMemcpy(treeR.data(), b.rng.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&cr, b.rng.ctrl + brick, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    }
     FILE *f = fopen(path, "wb");
     if (!f) return VR_ERR_IO;
     int64_t rootMin[3] = {0, 0, 0}, rootMax[3] = {b.g.X, b.g.Y, b.g.Z};
@@ -460,7 +470,9 @@ vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
               fwrite(&otd, 4, 1, f) == 1 && fwrite(&X, 8, 1, f) == 1 && fwrite(&Y, 8, 1, f) == 1 &&
               fwrite(&Z, 8, 1, f) == 1 && fwrite(&na, 8, 1, f) == 1 &&
               fwrite(c.distanceMap, 1, (size_t)mtd + 1, f) == (size_t)mtd + 1 &&
-              fwrite(tree.data(), 1, (size_t)bytes, f) == (size_t)bytes;
+              (!mrFile || fwrite(cr.distanceMap, 1, (size_t)mtd + 1, f) == (size_t)mtd + 1) &&
+              fwrite(tree.data(), 1, (size_t)bytes, f) == (size_t)bytes &&
+              (!mrFile || fwrite(treeR.data(), 1, (size_t)bytes, f) == (size_t)bytes);
     fclose(f);
     return ok ? VR_OK : VR_ERR_IO;
 }
@@ -499,6 +511,59 @@ vr_status vr_brickset_open(vr_brickset **out, const char *path)
     rc = vr_brickset_set_tree(h, 0, tree.data(), (int64_t)tree.size(), na, dmap.data(), mtd + 1);
     if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }
     h->s.openTreeBytes[0] = openBytes;
+    *out = h;
+    return VR_OK;
+}
+
+// MidRangeTree files (M.cpp:753-785).  The reference's own reader (M.cpp:787-833) mis-sizes both streams by
+// 4 bytes (it subtracts three of the four int64 header fields before halving), so the range stream it reads
+// back is shifted; there is nothing to match there.  This reader returns exactly what save() wrote.
+vr_status vr_brickset_open_variant(vr_brickset **out, const char *path, int32_t variant)
+{
+    if (!out || !path) return VR_ERR_INVALID;
+    if (variant != VR_VARIANT_MIDRANGE) {
+        if (variant != VR_VARIANT_RECOVER && variant != VR_VARIANT_GUARDED) return VR_ERR_INVALID;
+        return vr_brickset_open(out, path);
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) return VR_ERR_IO;
+    fseek(f, 0, SEEK_END);
+    const int64_t fileSize = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    int64_t rootMin[3], rootMax[3], X, Y, Z, na;
+    int32_t mtd, otd;
+    bool ok = fread(rootMin, 8, 3, f) == 3 && fread(rootMax, 8, 3, f) == 3 && fread(&mtd, 4, 1, f) == 1 &&
+              fread(&otd, 4, 1, f) == 1 && fread(&X, 8, 1, f) == 1 && fread(&Y, 8, 1, f) == 1 &&
+              fread(&Z, 8, 1, f) == 1 && fread(&na, 8, 1, f) == 1;
+    if (!ok || mtd < VR_CHAIN_LEVELS || mtd >= VR_MAX_DEPTH || na <= 0) { fclose(f); return VR_ERR_FORMAT; }
+    const int64_t have = fileSize - (88 + 2 * ((int64_t)mtd + 1));
+    const int64_t T = have / 2;
+    if (have < 0 || (have & 1) || T != (na + 3) / 4) { fclose(f); return VR_ERR_FORMAT; }
+    std::vector<uint8_t> dmap((size_t)mtd + 1), dmapR((size_t)mtd + 1), tree((size_t)T), treeR((size_t)T);
+    ok = fread(dmap.data(), 1, dmap.size(), f) == dmap.size() && fread(dmapR.data(), 1, dmapR.size(), f) == dmapR.size() &&
+         fread(tree.data(), 1, tree.size(), f) == tree.size() && fread(treeR.data(), 1, treeR.size(), f) == treeR.size();
+    fclose(f);
+    if (!ok) return VR_ERR_IO;
+    int64_t dims[3] = {X, Y, Z};
+    vr_brickset *h = nullptr;
+    vr_status rc = vr_brickset_create(&h, 1, dims, 6, 5, VR_VARIANT_MIDRANGE);
+    if (rc != VR_OK) return rc;
+    if (h->s.D != otd || h->s.maxDepth != mtd) { vr_brickset_destroy(h); return VR_ERR_FORMAT; }
+    rc = vr_brickset_set_tree(h, 0, tree.data(), (int64_t)tree.size(), na, dmap.data(), mtd + 1);
+    if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }
+    BrickSet &b = h->s;
+    Ctrl cr;
+    memset(&cr, 0, sizeof(Ctrl));
+    cr.numActive = (unsigned long long)na;
+    memcpy(cr.distanceMap, dmapR.data(), (size_t)mtd + 1);
+    hipError_t e = hipSuccess;
+    if (!b.rng.ctrl) e = hipMalloc(&b.rng.ctrl, sizeof(Ctrl));
+    if (e == hipSuccess && !b.rng.tree) e = hipMalloc(&b.rng.tree, (size_t)b.treeCap);
+    if (e == hipSuccess) e = hipMemcpy(b.rng.ctrl, &cr, sizeof(Ctrl), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(b.rng.tree, 0, (size_t)b.treeCap);
+    if (e == hipSuccess) e = hipMemcpy(b.rng.tree, treeR.data(), (size_t)T, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { vr_brickset_destroy(h); return VR_ERR_NO_DEVICE; }
+    b.foreignRange = true;
     *out = h;
     return VR_OK;
 }
