@@ -182,7 +182,7 @@ k_decode_tile(TileArgs a)
     __shared__ uint32_t strS[DEC_WAVES][DEC_SW * 64];   // [word][lane]
     __shared__ uint8_t stkS[DEC_WAVES][8 * 64];         // [level][lane]
     __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
-    __shared__ uint32_t lutS[32];    // tree-token action table (built below from dmS)
+    __shared__ uint32_t lutP[128];   // tree-token action table [level][code][next code] (built below from dmS)
     __shared__ uint32_t lutC1[256], lutC2[64];   // grown-branch tables: branch tokens 1-4 and 5-7
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
@@ -200,20 +200,36 @@ k_decode_tile(TileArgs a)
         dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        // tree-token action table: [level j][code]
-        const int key = threadIdx.x, j = key >> 2, tok = key & 3;
-        const bool is3 = tok == 3, lf = !is3 && j == 6;
-        const int desc = (!is3 && j < 6) ? 1 : 0;
-        const int term = (is3 || lf) ? 1 : 0;                 // a leaf's branch is consumed in the same step
-        const int count = is3 ? (64 >> (j > 6 ? 6 : j)) : 1;
-        const int dist = dmS[j > 6 ? 0 : j];
-        const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
-        const int single = (term && count == 1) ? 1 : 0, fillc = (term && count > 1) ? count : 0;
-        // row 7 (keys 28..31) is the no-op entry idle lanes read: delta 0, 0 bits consumed, no flags
-        lutS[key] = j == 7 ? 256u
-                           : ((uint32_t)(delta + 256) | (2u << 10) | ((uint32_t)term << 12) | ((uint32_t)desc << 13) |
-                              ((uint32_t)(lf ? 1 : 0) << 14) | ((uint32_t)fillc << 20) | ((uint32_t)single << 27));
+    if (threadIdx.x < 128) {
+        // tree-token action table, keyed by (level j, the node's code, the next token): a node that descends
+        // is handled together with its left child, whose token follows it immediately.  Packed:
+        //   [0:9) delta of the node + 256   [9:18) delta of the left child + 256 (256 = none)
+        //   18 second (left child handled)  [19:21) descents (0: node terminal, 1: child terminal -> continue at the
+        //   node's right child, 2: continue at the child's left child)  21 lf (a voxel leaf with a branch behind it)
+        //   22 single (one voxel to emit)   [23:30) fill count of a pruned node   30 terminal   31 valid
+        const int key = threadIdx.x, j = key >> 4, t0 = key & 3, t1 = (key >> 2) & 3;
+        uint32_t ent = 256u | (256u << 9);              // row 7: the no-op entry idle lanes read
+        if (j < 7) {
+            const auto delta = [&](int tok, int lvl) { const int d = dmS[lvl]; return tok == 1 ? d : (tok == 2 ? -d : 0); };
+            const bool is30 = t0 == 3, desc0 = !is30 && j < 6;
+            int d1 = 0, second = 0, ndesc = 0, lf, single, fillc;
+            if (!desc0) {
+                lf = (j == 6 && !is30) ? 1 : 0;
+                fillc = (is30 && j < 6) ? (64 >> j) : 0;
+                single = j == 6 ? 1 : 0;
+            } else {
+                const bool is31 = t1 == 3, leaf1 = j + 1 == 6;
+                second = 1;
+                d1 = delta(t1, j + 1);
+                ndesc = (!is31 && !leaf1) ? 2 : 1;
+                lf = (leaf1 && !is31) ? 1 : 0;
+                fillc = (is31 && !leaf1) ? (64 >> (j + 1)) : 0;
+                single = leaf1 ? 1 : 0;
+            }
+            ent = (uint32_t)(delta(t0, j) + 256) | ((uint32_t)(d1 + 256) << 9) | ((uint32_t)second << 18) | ((uint32_t)ndesc << 19) |
+                  ((uint32_t)lf << 21) | ((uint32_t)single << 22) | ((uint32_t)fillc << 23) | ((ndesc < 2 ? 1u : 0u) << 30) | (1u << 31);
+        }
+        lutP[key] = ent;
     }
     {
         // grown-branch tables: compose v -> min(max(v + A, LO), HI) over steps first..first+n-1
@@ -294,33 +310,37 @@ k_decode_tile(TileArgs a)
                 const uint32_t w0 = str[k * 64 + lane], w1 = str[(k + 1) * 64 + lane];
                 const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);   // 16 tokens ahead
                 const uint32_t j = (31u - (uint32_t)__clz((int)p)) & 7u;
-                // idle lanes read the all-zero row 7: nothing is consumed, written or changed
-                const uint32_t e = lutS[tk ? j * 4u + (x & 3u) : 28u];
-                const uint32_t e1 = lutC1[(x >> 2) & 255u], e2 = lutC2[(x >> 10) & 63u];
+                // idle lanes read the no-op row 7: nothing is consumed, written or changed
+                const uint32_t e = lutP[(tk ? j : 7u) * 16u + (x & 15u)];
+                // the one voxel leaf of this step, if any, is the node itself (level 6) or its left child (level 5)
+                const uint32_t xc = x >> (j == 6u ? 2u : 4u);
+                const uint32_t e1 = lutC1[xc & 255u], e2 = lutC2[(xc >> 8) & 63u];
                 const int sv = stk[((j + 7u) & 7u) * 64 + lane];
-                const int nv = med3i(sv + (int)(e & 1023u) - 256, 0, 255);      // decoder step R.cpp:783-787
+                const int nv = med3i(sv + (int)(e & 511u) - 256, 0, 255);        // decoder step R.cpp:783-787
+                const int nv1 = med3i(nv + (int)((e >> 9) & 511u) - 256, 0, 255);  // ... and the left child's
+                const uint32_t second = (e >> 18) & 1u, ndesc = (e >> 19) & 3u;
+                const int vb = second ? nv1 : nv;
                 // grown branch of a voxel leaf: first 4 tokens, then (unless terminated) 3 more
-                const int b1 = med3i(nv + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
+                const int b1 = med3i(vb + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
                 const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
-                const uint32_t lf = (e >> 14) & 1u;                              // voxel leaf with a branch behind it
+                const uint32_t lf = (e >> 21) & 1u;                              // voxel leaf with a branch behind it
                 const uint32_t more = lf & ~(e1 >> 29);                          // first four were no terminator
                 const uint32_t clen = ((e1 >> 26) & 7u) + (more ? ((e2 >> 26) & 7u) : 0u);
-                const int vo = lf ? (more ? b2 : b1) : nv;
-                const uint32_t desc = (e >> 13) & 1u;
-                const bool t = ((e >> 12) & 1u) != 0u;
-                const uint32_t single = (e >> 27) & 1u;
-                const uint32_t fillc = (e >> 20) & 127u;
+                const int vo = lf ? (more ? b2 : b1) : vb;
+                const bool t = ((e >> 30) & 1u) != 0u;
+                const uint32_t single = (e >> 22) & 1u;
+                const uint32_t fillc = (e >> 23) & 127u;
                 v = tk ? vo : v;
-                stk[(desc ? j : 6u) * 64 + lane] = (uint8_t)nv;
-                p <<= desc;
-                bitpos += ((e >> 10) & 3u) + (lf ? 2u * clen : 0u);
+                stk[(ndesc >= 1u ? j : 6u) * 64 + lane] = (uint8_t)nv;
+                stk[(ndesc == 2u ? j + 1u : 6u) * 64 + lane] = (uint8_t)nv1;
+                bitpos += 2u * (e >> 31) + 2u * second + (lf ? 2u * clen : 0u);
                 tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)vo;
                 leaf += (int)single;
                 fill = fillc ? (int)fillc : fill;
                 uint32_t np = p + 1u;
                 np >>= (__ffs((int)np) - 1);
-                const bool parked = t && np == 1u;              // no further tokens are mine
-                p = t ? (parked ? 0x80000000u : np) : p;
+                const bool parked = t && ndesc == 0u && np == 1u;   // no further tokens are mine
+                p = ndesc == 2u ? p << 2 : (ndesc == 1u ? (p << 1) | 1u : (t ? (parked ? 0x80000000u : np) : p));
                 done = done || (parked && fill == 0);
             }
         }
