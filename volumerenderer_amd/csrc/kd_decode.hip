@@ -319,7 +319,7 @@ k_decode_tile(TileArgs a)
                 const int nv = med3i(sv + (int)(e & 511u) - 256, 0, 255);        // decoder step R.cpp:783-787
                 const int nv1 = med3i(nv + (int)((e >> 9) & 511u) - 256, 0, 255);  // ... and the left child's
                 const uint32_t second = (e >> 18) & 1u, ndesc = (e >> 19) & 3u;
-                const int vb = second ? nv1 : nv;
+                const int vb = nv1;                                              // == nv when there is no second node (delta 0)
                 // grown branch of a voxel leaf: first 4 tokens, then (unless terminated) 3 more
                 const int b1 = med3i(vb + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
                 const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
