@@ -159,7 +159,7 @@ struct TileArgs {
 
 #define DEC_WAVES 4
 #define DEC_DUMMY_ROW 64
-#define DEC_SW 32            // staged words per lane (usable lookahead: DEC_SW-2 words per stage)
+#define DEC_SW 31            // staged words per lane (usable lookahead: DEC_SW-2 words per stage); 31 keeps 3 blocks per CU in LDS
 
 __device__ __forceinline__ int med3i(int x, int lo, int hi)
 {   // min(max(x, lo), hi) for lo <= hi in one instruction
@@ -182,7 +182,8 @@ k_decode_tile(TileArgs a)
     __shared__ uint32_t strS[DEC_WAVES][DEC_SW * 64];   // [word][lane]
     __shared__ uint8_t stkS[DEC_WAVES][8 * 64];         // [level][lane]
     __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
-    __shared__ uint32_t lutP[128];   // tree-token action table [level][code][next code] (built below from dmS)
+    __shared__ uint32_t lutP[260];   // tree-token action table [level][code][next code] (built below from dmS);
+                                     // [129 + key]: second word (one bank further: both come with one ds_read2_b32)
     __shared__ uint32_t lutC1[256], lutC2[64];   // grown-branch tables: branch tokens 1-4 and 5-7
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
@@ -207,8 +208,12 @@ k_decode_tile(TileArgs a)
         //   18 second (left child handled)  [19:21) descents (0: node terminal, 1: child terminal -> continue at the
         //   node's right child, 2: continue at the child's left child)  21 lf (a voxel leaf with a branch behind it)
         //   22 single (one voxel to emit)   [23:30) fill count of a pruned node   30 terminal   31 valid
+        // second word, what the step would otherwise derive with compares: [0:10) byte offset of the value-stack
+        // row the node's value goes to (scratch row 6 when it does not descend), [10:20) same for the child,
+        // [20:23) bits of tree tokens consumed, [23:25) path shift, 25 path "or 1" (continue at the right child)
         const int key = threadIdx.x, j = key >> 4, t0 = key & 3, t1 = (key >> 2) & 3;
         uint32_t ent = 256u | (256u << 9);              // row 7: the no-op entry idle lanes read
+        uint32_t ent2 = (6u * 64u) | ((6u * 64u) << 10);
         if (j < 7) {
             const auto delta = [&](int tok, int lvl) { const int d = dmS[lvl]; return tok == 1 ? d : (tok == 2 ? -d : 0); };
             const bool is30 = t0 == 3, desc0 = !is30 && j < 6;
@@ -228,8 +233,11 @@ k_decode_tile(TileArgs a)
             }
             ent = (uint32_t)(delta(t0, j) + 256) | ((uint32_t)(d1 + 256) << 9) | ((uint32_t)second << 18) | ((uint32_t)ndesc << 19) |
                   ((uint32_t)lf << 21) | ((uint32_t)single << 22) | ((uint32_t)fillc << 23) | ((ndesc < 2 ? 1u : 0u) << 30) | (1u << 31);
+            ent2 = (uint32_t)((ndesc >= 1 ? j : 6) * 64) | ((uint32_t)((ndesc == 2 ? j + 1 : 6) * 64) << 10) |
+                   ((uint32_t)(2 + 2 * second) << 20) | ((uint32_t)ndesc << 23) | ((ndesc == 1 ? 1u : 0u) << 25);
         }
         lutP[key] = ent;
+        lutP[129 + key] = ent2;
     }
     {
         // grown-branch tables: compose v -> min(max(v + A, LO), HI) over steps first..first+n-1
@@ -311,14 +319,15 @@ k_decode_tile(TileArgs a)
                 const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);   // 16 tokens ahead
                 const uint32_t j = (31u - (uint32_t)__clz((int)p)) & 7u;
                 // idle lanes read the no-op row 7: nothing is consumed, written or changed
-                const uint32_t e = lutP[(tk ? j : 7u) * 16u + (x & 15u)];
+                const uint32_t ei = (tk ? j : 7u) * 16u + (x & 15u);
+                const uint32_t e = lutP[ei], f = lutP[ei + 129u];
                 // the one voxel leaf of this step, if any, is the node itself (level 6) or its left child (level 5)
                 const uint32_t xc = x >> (j == 6u ? 2u : 4u);
                 const uint32_t e1 = lutC1[xc & 255u], e2 = lutC2[(xc >> 8) & 63u];
                 const int sv = stk[((j + 7u) & 7u) * 64 + lane];
                 const int nv = med3i(sv + (int)(e & 511u) - 256, 0, 255);        // decoder step R.cpp:783-787
                 const int nv1 = med3i(nv + (int)((e >> 9) & 511u) - 256, 0, 255);  // ... and the left child's
-                const uint32_t second = (e >> 18) & 1u, ndesc = (e >> 19) & 3u;
+                const uint32_t ndesc = (e >> 19) & 3u;
                 const int vb = nv1;                                              // == nv when there is no second node (delta 0)
                 // grown branch of a voxel leaf: first 4 tokens, then (unless terminated) 3 more
                 const int b1 = med3i(vb + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
@@ -331,16 +340,17 @@ k_decode_tile(TileArgs a)
                 const uint32_t single = (e >> 22) & 1u;
                 const uint32_t fillc = (e >> 23) & 127u;
                 v = tk ? vo : v;
-                stk[(ndesc >= 1u ? j : 6u) * 64 + lane] = (uint8_t)nv;
-                stk[(ndesc == 2u ? j + 1u : 6u) * 64 + lane] = (uint8_t)nv1;
-                bitpos += 2u * (e >> 31) + 2u * second + (lf ? 2u * clen : 0u);
+                stk[(f & 1023u) + lane] = (uint8_t)nv;
+                stk[((f >> 10) & 1023u) + lane] = (uint8_t)nv1;
+                bitpos += ((f >> 20) & 7u) + (lf ? 2u * clen : 0u);
                 tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)vo;
                 leaf += (int)single;
                 fill = fillc ? (int)fillc : fill;
                 uint32_t np = p + 1u;
                 np >>= (__ffs((int)np) - 1);
                 const bool parked = t && ndesc == 0u && np == 1u;   // no further tokens are mine
-                p = ndesc == 2u ? p << 2 : (ndesc == 1u ? (p << 1) | 1u : (t ? (parked ? 0x80000000u : np) : p));
+                const uint32_t pd = (p << ((f >> 23) & 3u)) | ((f >> 25) & 1u);   // descents: continue below
+                p = (t && ndesc == 0u) ? (parked ? 0x80000000u : np) : pd;
                 done = done || (parked && fill == 0);
             }
         }
