@@ -278,13 +278,10 @@ __global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *
 #define EST_ROUNDS 4        // round 0 uses a 4-wide window, later rounds EST_CAND-wide recentred ones
 #define EST_HEAD 4096
 
-// Segment summaries of one brick, structure of arrays: field f of candidate ci of segment seg lives at
-// ((f * EST_CAND + ci) * summStride + seg), so the walking wave reads 64 consecutive segments as one line.
-enum { EST_F_SUMS = 0, EST_F_SUMC = 1, EST_F_A = 2, EST_F_B = 3 };
-__device__ __forceinline__ int64_t est_at(int f, int ci, int64_t summStride, uint32_t seg)
-{
-    return (int64_t)(f * EST_CAND + ci) * summStride + seg;
-}
+// Segment summaries of one brick: 32 dwords per segment, candidate ci at [ci*4 .. ci*4+3] = (sumS, sumC, A, B).
+// k_est_summ writes a candidate's record with one 16-byte transaction (four lanes), the walking wave reads it
+// with one 16-byte load per lane.
+__device__ __forceinline__ int64_t est_at(int ci, uint32_t seg) { return (int64_t)seg * (4 * EST_CAND) + ci * 4; }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
@@ -410,7 +407,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     const int Tbase = c.estTbase;
     uint32_t *out = summ + (int64_t)brick * summStride * (4 * EST_CAND);
     if (__ballot(anyPd != 0) == 0ull) {      // parents reproduce the truths exactly (constant regions): nothing counts
-        if (lane < 4 * nc) out[est_at(lane / nc, lane % nc, summStride, seg)] = 0;
+        if (lane < 4 * nc) out[est_at(0, seg) + lane] = 0;
         continue;
     }
 #pragma unroll 1
@@ -443,12 +440,8 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         a = wave_max_i32_dpp(a);
         b = -wave_max_i32_dpp(-b);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (lane == 0) {
-            out[est_at(EST_F_SUMS, ci, summStride, seg)] = tot & 0xFFFFFu;
-            out[est_at(EST_F_SUMC, ci, summStride, seg)] = tot >> 20;
-            out[est_at(EST_F_A, ci, summStride, seg)] = (uint32_t)a;
-            out[est_at(EST_F_B, ci, summStride, seg)] = (uint32_t)b;
-        }
+        if (lane < 4)
+            out[est_at(ci, seg) + lane] = lane == 0 ? (tot & 0xFFFFFu) : (lane == 1 ? (tot >> 20) : (lane == 2 ? (uint32_t)a : (uint32_t)b));
     }
     }
 }
@@ -495,15 +488,15 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
         int A = INT32_MIN, B = INT32_MAX;
         if (preSeg == seg && preCi == ci) { ss = preS; sc = preC; A = preA; B = preB; }
         else if (valid) {
-            ss = sm[est_at(EST_F_SUMS, (int)ci, summStride, k)]; sc = sm[est_at(EST_F_SUMC, (int)ci, summStride, k)];
-            A = (int)sm[est_at(EST_F_A, (int)ci, summStride, k)]; B = (int)sm[est_at(EST_F_B, (int)ci, summStride, k)];
+            const uint4 r = *(const uint4 *)(sm + est_at((int)ci, k));
+            ss = r.x; sc = r.y; A = (int)r.z; B = (int)r.w;
         }
         {
             const uint32_t k2 = k + 64;
             preSeg = seg + 64; preCi = ci; preS = 0; preC = 0; preA = INT32_MIN; preB = INT32_MAX;
             if (k2 < nseg) {
-                preS = sm[est_at(EST_F_SUMS, (int)ci, summStride, k2)]; preC = sm[est_at(EST_F_SUMC, (int)ci, summStride, k2)];
-                preA = (int)sm[est_at(EST_F_A, (int)ci, summStride, k2)]; preB = (int)sm[est_at(EST_F_B, (int)ci, summStride, k2)];
+                const uint4 r = *(const uint4 *)(sm + est_at((int)ci, k2));
+                preS = r.x; preC = r.y; preA = (int)r.z; preB = (int)r.w;
             }
         }
         const uint32_t si = wave_incl_scan_u32(ss, lane), sci = wave_incl_scan_u32(sc, lane);
