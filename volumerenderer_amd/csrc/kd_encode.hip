@@ -385,11 +385,21 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     const uint32_t n = 1u << d;
     if (c.constBrick || c.estDone) return;
     // segments from where the walk stands; later rounds run on a small grid (most bricks are done by then)
-    for (uint32_t seg = (uint32_t)c.estSeg + blockIdx.x * 4 + (threadIdx.x >> 6); seg < n / EST_SEG; seg += gridDim.x * 4) {
-    const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + (size_t)seg * EST_SEG + lane * 16;
-    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride + (((size_t)seg * EST_SEG + lane * 16) >> 1);
-    const uint4 tv = *(const uint4 *)T;
-    const uint2 pv = *(const uint2 *)P;
+    const uint8_t *Tl = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + lane * 16;
+    const uint8_t *Pl = rb.b[c.par] + (int64_t)brick * leafStride + lane * 8;
+    const uint32_t nseg = n / EST_SEG, seg0 = (uint32_t)c.estSeg + blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the next segment's bytes are in flight while this one is summarised (a wave's single load round trip is
+    // what bounds this kernel: twice the bytes in flight per wave)
+    uint4 tvN = make_uint4(0, 0, 0, 0);
+    uint2 pvN = make_uint2(0, 0);
+    if (seg0 < nseg) { tvN = *(const uint4 *)(Tl + (size_t)seg0 * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)seg0 * (EST_SEG / 2)); }
+    for (uint32_t seg = seg0; seg < nseg; seg += gridDim.x * 4) {
+    const uint4 tv = tvN;
+    const uint2 pv = pvN;
+    {
+        const uint32_t sn = seg + gridDim.x * 4;
+        if (sn < nseg) { tvN = *(const uint4 *)(Tl + (size_t)sn * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)sn * (EST_SEG / 2)); }
+    }
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w};
     vr_s16x2 pd[8], h[8];
     uint32_t anyPd = 0;
@@ -2046,7 +2056,7 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
             for (int r = 0; r < EST_ROUNDS; ++r) {
                 const int nc = r == 0 ? 4 : EST_CAND;
-                const unsigned gx = r == 0 ? cdiv(nseg, 4) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);
+                const unsigned gx = r == 0 ? cdiv(nseg, 16) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);   // four segments per wave first
                 hipLaunchKernelGGL(k_est_summ, dim3(gx, B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
                                    bs->heapStride, rb, bs->leafStride, (uint32_t *)bs->estSumm, bs->estSummStride);
                 hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, EST_CAND,
