@@ -1242,12 +1242,22 @@ struct PruneEmitArgs {
     int64_t nIdx;
 };
 
-__device__ __forceinline__ uint32_t *pe_stage(uint8_t *temp, int64_t heapStride, const ReconBufs &rb, int ra, int rbI,
-                                              int64_t leafStride, int brick, uint32_t blk, uint32_t w)
+// The three 4 KiB pieces of a block's staging area, resolved once per thread: indexing ReconBufs (a kernel
+// argument) with a run-time index inside a loop would be a load from the argument segment per access.
+struct PeStage { uint32_t *p0, *p1, *p2; };
+__device__ __forceinline__ PeStage pe_stage_of(uint8_t *temp, int64_t heapStride, const ReconBufs &rb, int ra, int rbI,
+                                               int64_t leafStride, int brick, uint32_t blk)
 {
-    uint8_t *basePtr = w < 1024u ? temp + (int64_t)brick * heapStride
-                                 : (w < 2048u ? rb.b[ra] : rb.b[rbI]) + (int64_t)brick * leafStride;
-    return (uint32_t *)(basePtr + (int64_t)blk * 4096) + (w & 1023u);
+    PeStage s;
+    uint8_t *b1 = ra == 0 ? rb.b[0] : (ra == 1 ? rb.b[1] : rb.b[2]), *b2 = rbI == 0 ? rb.b[0] : (rbI == 1 ? rb.b[1] : rb.b[2]);
+    s.p0 = (uint32_t *)(temp + (int64_t)brick * heapStride + (int64_t)blk * 4096);
+    s.p1 = (uint32_t *)(b1 + (int64_t)brick * leafStride + (int64_t)blk * 4096);
+    s.p2 = (uint32_t *)(b2 + (int64_t)brick * leafStride + (int64_t)blk * 4096);
+    return s;
+}
+__device__ __forceinline__ uint32_t *pe_stage(const PeStage &s, uint32_t w)
+{
+    return (w < 1024u ? s.p0 : (w < 2048u ? s.p1 : s.p2)) + (w & 1023u);
 }
 
 __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
@@ -1496,8 +1506,8 @@ k_prune_emit12(PruneEmitArgs a)
         a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + (t >> 2)] = aliveAtDs ? pos + (uint32_t)preDs : VR_IDX_DEAD;
     __syncthreads();
     const uint32_t nw = (tot + 15u) >> 4;
-    for (uint32_t i = t; i < nw; i += 256)
-        *pe_stage(a.temp, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk, i) = W[i];
+    const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk);
+    for (uint32_t i = t; i < nw; i += 256) *pe_stage(stg, i) = W[i];
 }
 
 
@@ -1961,8 +1971,7 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
     const uint32_t phase = g0 & 15u;
     const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
     uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
-    uint8_t *tempW = const_cast<uint8_t *>(a.temp);
-    const int ra = c.ra, rbI = c.rb;
+    const PeStage stg = pe_stage_of(const_cast<uint8_t *>(a.temp), a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk);
     for (uint32_t i0 = 0; i0 < nwo; i0 += 256) {        // four words per lane and trip: eight loads in flight
         uint32_t lo[4], hi[4];
         int sbv[4];
@@ -1971,8 +1980,8 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
             const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
             const int so = 2 * (16 * (int)i - (int)phase) - 2 * nsp, sw = so >> 5;     // staged bit offset (floor division)
             sbv[u] = so & 31;
-            lo[u] = (cnt && i < nwo && sw >= 0 && sw < nws) ? *pe_stage(tempW, a.heapStride, a.rb, ra, rbI, a.leafStride, brick, blk, (uint32_t)sw) : 0u;
-            hi[u] = (cnt && i < nwo && sw + 1 >= 0 && sw + 1 < nws) ? *pe_stage(tempW, a.heapStride, a.rb, ra, rbI, a.leafStride, brick, blk, (uint32_t)(sw + 1)) : 0u;
+            lo[u] = (cnt && i < nwo && sw >= 0 && sw < nws) ? *pe_stage(stg, (uint32_t)sw) : 0u;
+            hi[u] = (cnt && i < nwo && sw + 1 >= 0 && sw + 1 < nws) ? *pe_stage(stg, (uint32_t)(sw + 1)) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
