@@ -159,7 +159,7 @@ struct TileArgs {
 
 #define DEC_WAVES 4
 #define DEC_DUMMY_ROW 64
-#define DEC_SW 31            // staged words per lane (usable lookahead: DEC_SW-2 words per stage); 31 keeps 3 blocks per CU in LDS
+#define DEC_SW 19            // staged words per lane (usable lookahead: DEC_SW-2 words per stage); 19 = four blocks per CU in LDS (40 480 B each)
 
 __device__ __forceinline__ int med3i(int x, int lo, int hi)
 {   // min(max(x, lo), hi) for lo <= hi in one instruction
