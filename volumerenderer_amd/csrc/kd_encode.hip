@@ -275,7 +275,7 @@ __global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *
 //               that segment node by node.
 #define EST_SEG 1024
 #define EST_CAND 8          // widest candidate window (records hold EST_CAND entries)
-#define EST_ROUNDS 4        // round 0 uses a 4-wide window, later rounds EST_CAND-wide recentred ones
+#define EST_ROUNDS 5        // rounds 0,1 use a 4-wide window, later rounds EST_CAND-wide recentred ones; the last one walks exactly if it must
 #define EST_HEAD 4096
 
 // Segment summaries of one brick: 32 dwords per segment, candidate ci at [ci*4 .. ci*4+3] = (sumS, sumC, A, B).
@@ -2064,11 +2064,11 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint
         if (n > EST_HEAD) {
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
             for (int r = 0; r < EST_ROUNDS; ++r) {
-                const int nc = r == 0 ? 4 : EST_CAND;
+                const int nc = r < 2 ? 4 : EST_CAND, ncNext = r + 1 < 2 ? 4 : EST_CAND;   // two 4-wide windows, then 8-wide ones
                 const unsigned gx = r == 0 ? cdiv(nseg, 16) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);   // four segments per wave first
                 hipLaunchKernelGGL(k_est_summ, dim3(gx, B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
                                    bs->heapStride, rb, bs->leafStride, (uint32_t *)bs->estSumm, bs->estSummStride);
-                hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, EST_CAND,
+                hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, ncNext,
                                    r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
                                    (const uint32_t *)bs->estSumm, bs->estSummStride);
             }
