@@ -303,3 +303,31 @@ def test_midrange_file_roundtrip(vr, oracle, tmp_path):
         vr.MidRangeTree().open(str(tmp_path / "missing.bin"))
     with pytest.raises(vr.VrError):
         vr.MidRangeTree().open(os.path.join(os.path.dirname(__file__), "golden", "ref_sphere_n3_16_tol1_ep2.tree.bin"))
+
+
+def test_bench_workload_bricks_match_oracle(vr, oracle):
+    """The bench's own brick shape and field (256x256x128 = depth 23, the fused 12-level kernels,
+    XCD-swizzled pyramid, tile decode): three bricks through the interface, bit-exact with the oracle."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    bd, gd = (256, 256, 128), (256, 256, 384)
+    vox4 = bench.make_volume_gpu(torch, gd, bd, seed=12345, kind="rm_volume")
+    host = vox4.cpu().numpy()
+    bs = vr.BrickSet(3, bd, 1, 2)
+    bs.build(vox4.reshape(-1))
+    dec = bs.decode().cpu().numpy().reshape(host.shape)
+    cut = bs.decode(cut_depth=20).cpu().numpy().reshape(host.shape)
+    assert len({host[b].tobytes() for b in range(3)}) == 3 and host[1].min() != host[1].max()
+    for b in range(3):
+        ref = oracle.OracleTree(host[b].copy(), tolerance=1, max_epochs=2).build()
+        info = bs.info(b)
+        assert info["orig_tree_depth"] == 23 and info["num_active_nodes"] == ref.numActiveNodes
+        assert list(bs.distance_map(b)) == list(ref.distanceMap)
+        assert oracle.fnv1a64(bs.tree(b)) == oracle.fnv1a64(ref.tree)
+        assert np.array_equal(dec[b], ref.levelCut())
+        assert np.array_equal(cut[b], ref.levelCutProgressive(20))
+        st = ref.leaf_stats()
+        assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"]
+        assert info["num_reverts"] == ref.numReverts
