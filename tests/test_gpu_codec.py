@@ -331,3 +331,23 @@ def test_bench_workload_bricks_match_oracle(vr, oracle):
         st = ref.leaf_stats()
         assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"]
         assert info["num_reverts"] == ref.numReverts
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_estimator_threshold_drift(vr, oracle, seed):
+    """Slabs of very different noise amplitude make the running-mean threshold drift far and fast inside a
+    level: the candidate windows are left repeatedly (later rounds, the exact last-resort walk).  The result
+    must still be the serial one."""
+    rng = np.random.default_rng(seed)
+    n = 64
+    amp = np.array([0, 60, 2, 120, 0, 8, 200, 1] * (n // 8))[:n]
+    rng.shuffle(amp)
+    vol = np.zeros((n, n, n), np.int64) + 128
+    for z in range(n):
+        if amp[z]:
+            vol[z] += rng.integers(-amp[z] // 2, amp[z] // 2 + 1, (n, n))
+    # Morton order interleaves z with x, y: the drift happens along every level, not once
+    vol = np.clip(vol, 0, 255).astype(np.uint8)
+    for tol, ep in ((1, 2), (4, 5)):
+        check_case(vr, oracle, vol, tol, ep)
+    check_case(vr, oracle, np.ascontiguousarray(vol.transpose(2, 1, 0)), 1, 2)
