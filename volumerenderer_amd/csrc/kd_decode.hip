@@ -272,7 +272,11 @@ k_decode_tile(TileArgs a)
     const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
     const int val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
 
-    {
+    // a tile whose 64 subtrees all lie under pruned nodes (constant regions) needs no walk: one value per
+    // subtree goes to tile row 0 and the gather below reads every leaf from there
+    const bool waveDead = __ballot(off != VR_IDX_DEAD) == 0ull;
+    if (waveDead) tile[lane] = (uint8_t)val0;
+    else {
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
         const bool dead = off == VR_IDX_DEAD;
         bool done = false;
@@ -362,14 +366,15 @@ k_decode_tile(TileArgs a)
     const int jx = a.jx, jy = a.jy, jz = a.jz;
     const int c = lane & 7;
     uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16;
-    const int r1 = 1 << jx, r2 = 8 << jx;            // Morton rank steps of dx bit 0 / bit 1
+    const int live = waveDead ? 0 : 1;
+    const int r1 = live << jx, r2 = (8 * live) << jx;            // Morton rank steps of dx bit 0 / bit 1
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int R = st * 8 + (lane >> 3);
         const int y = R & 7, z = R >> 3;
         const int dy = y & 3, dz = z & 3;
         const int rb = ((dy & 1) << jy) | ((dy >> 1) << (3 + jy)) | ((dz & 1) << jz) | ((dz >> 1) << (3 + jz));
-        const uint8_t *src = tile + rb * 64 + 4 * c + 32 * (y >> 2);
+        const uint8_t *src = tile + rb * live * 64 + 4 * c + 32 * (y >> 2);
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
