@@ -716,6 +716,89 @@ __device__ inline double ctl_walk_block(double s, const uint8_t *__restrict__ T,
     return s;
 }
 
+// The same walk for a whole 1024-node block with 16 consecutive nodes per lane: one load round trip, the err^2
+// prefix sums built once (local prefix + one wave scan), and every crossing found by comparing each node's
+// prefix with the current bound -- instead of sixteen dependent 64-node steps.
+__device__ inline double ctl_walk_block16(double s, const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int dist,
+                                          uint32_t lo, int lane)
+{
+    const uint4 tv = *(const uint4 *)(T + lo + lane * 16);
+    const uint2 pv = *(const uint2 *)(P + (lo >> 1) + lane * 8);
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
+    const uint32_t d2 = (uint32_t)dist * 0x10001u;
+    uint32_t e[16], pre[16];          // err^2 of my nodes, inclusive prefix inside the lane
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
+        const vr_s16x2 er = enc_pair_err(c, d2);
+        e[2 * j] = (uint32_t)((int)er.x * (int)er.x);
+        e[2 * j + 1] = (uint32_t)((int)er.y * (int)er.y);
+        run += e[2 * j]; pre[2 * j] = run;
+        run += e[2 * j + 1]; pre[2 * j + 1] = run;
+    }
+    const uint32_t inclL = wave_incl_scan_add_dpp(run);       // < 2^27
+    const uint32_t baseL = inclL - run, total = (uint32_t)__builtin_amdgcn_readlane((int)inclL, 63);
+    uint32_t consumed = 0;
+    int startPos = 0;                                          // nodes before block-local position startPos are added
+    while (true) {
+        // first node at or after startPos whose addition (with everything before it) would leave the binade
+        int fail = 16;
+        if (s != 0.0) {
+            const double bound = next_pow2_above(s);
+#pragma unroll
+            for (int k = 15; k >= 0; --k)
+                if (lane * 16 + k >= startPos && !((s + (double)(baseL + pre[k] - consumed)) < bound)) fail = k;
+        }
+        const unsigned long long bad = __ballot(fail < 16);
+        if (bad == 0ull) { s = s + (double)(total - consumed); break; }
+        const int f = __ffsll((long long)bad) - 1;
+        const int kF = __builtin_amdgcn_readlane(fail, f);
+        uint32_t eF = 0, gF = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k == kF) { eF = e[k]; gF = baseL + pre[k]; }
+        eF = (uint32_t)__builtin_amdgcn_readlane((int)eF, f);
+        gF = (uint32_t)__builtin_amdgcn_readlane((int)gF, f);
+        s = s + (double)(gF - eF - consumed);   // exact: still inside the binade
+        s = s + (double)eF;                     // the reference's rounded add that crosses it
+        consumed = gF;
+        startPos = f * 16 + kF + 1;
+    }
+    return s;
+}
+
+// 64 partials (1024 nodes each) starting at block `base`, added in order: whole partials while the sum stays inside
+// its binade, the crossing block node by node
+__device__ inline double ctl_partials64(double s, const unsigned long long *__restrict__ be, uint32_t base, uint32_t nblk,
+                                        const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, int dist,
+                                        uint32_t n, int lane)
+{
+    const unsigned long long e2 = base + lane < nblk ? be[base + lane] : 0ull;
+    // two 32-bit DPP scans (24-bit limbs: 64 partials of < 2^27 each cannot overflow either)
+    const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 & 0xFFFFFFull)) +
+                                    ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 >> 24)) << 24);
+    const unsigned long long total = __shfl(incl, 63);
+    unsigned long long consumed = 0;
+    int start = 0;
+    while (true) {
+        bool ok = true;
+        // an integer-valued sum below 2^53 adds integers exactly whatever the binade
+        const bool sInt = (s == floor(s)) && (s + (double)(total - consumed)) < 9007199254740992.0;
+        if (lane >= start && !sInt) ok = (s + (double)(incl - consumed)) < next_pow2_above(s);
+        const unsigned long long bad = ~__ballot(ok);
+        if (bad == 0ull) { s = s + (double)(total - consumed); break; }
+        const int f = __ffsll((long long)bad) - 1;
+        const unsigned long long exclF = __shfl(incl - e2, f), inclF = __shfl(incl, f);
+        s = s + (double)(exclF - consumed);
+        uint32_t lo = (base + f) * FILL_NODES_PER_BLOCK, hi = lo + FILL_NODES_PER_BLOCK;
+        if (hi > n) hi = n;
+        s = (hi - lo == 1024u && d > 0) ? ctl_walk_block16(s, T, P, dist, lo, lane) : ctl_walk_block(s, T, P, d, dist, lo, hi, lane);
+        consumed = inclF;
+        start = f + 1;
+    }
+    return s;
+}
+
 __global__ void __launch_bounds__(64)
 k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride,
           ReconBufs rb, int64_t leafStride, const unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
@@ -732,29 +815,39 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
         const int dist = (int)(uint8_t)c.currentDistance;
         const uint32_t nblk = (n + FILL_NODES_PER_BLOCK - 1) / FILL_NODES_PER_BLOCK;
         const unsigned long long *be = blockErr + (int64_t)brick * nErrBlk;
-        unsigned long long pre = (uint32_t)lane < nblk ? be[lane] : 0ull;     // the next 64 partials are in flight
-        for (uint32_t base = 0; base < nblk; base += 64) {                  // while these are added
-            const unsigned long long e2 = pre;
-            pre = base + 64 + lane < nblk ? be[base + 64 + lane] : 0ull;
-            // two 32-bit DPP scans (24-bit limbs: 64 partials of < 2^27 each cannot overflow either)
-            const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 & 0xFFFFFFull)) +
-                                            ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 >> 24)) << 24);
+        // Two levels: every lane sums one chunk of 64 partials (64 independent loads, no dependent steps), the wave
+        // adds whole chunks in order while the running double provably stays inside its binade, and only a chunk in
+        // which it crosses a power of two is opened (ctl_partials64, which opens only the crossing block).  A level
+        // has ~log2 crossings, so this touches a handful of chunks instead of stepping through all of them.
+        const uint32_t nchunk = (nblk + 63u) >> 6;
+        for (uint32_t cb = 0; cb < nchunk; cb += 64) {
+            const uint32_t ch = cb + (uint32_t)lane;
+            unsigned long long tot = 0;
+            if (ch < nchunk) {
+                const unsigned long long *q = be + (size_t)ch * 64;
+                const uint32_t m = nblk - ch * 64 < 64u ? nblk - ch * 64 : 64u;
+                if (m == 64u) {
+#pragma unroll 8
+                    for (int k = 0; k < 64; ++k) tot += q[k];
+                } else
+                    for (uint32_t k = 0; k < m; ++k) tot += q[k];
+            }
+            // chunk totals < 2^33: 24-bit low limbs (sum < 2^30) and high limbs < 2^9 (sum < 2^15)
+            const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(tot & 0xFFFFFFull)) +
+                                            ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(tot >> 24)) << 24);
             const unsigned long long total = __shfl(incl, 63);
             unsigned long long consumed = 0;
             int start = 0;
             while (true) {
                 bool ok = true;
-                // an integer-valued sum below 2^53 adds integers exactly whatever the binade
                 const bool sInt = (s == floor(s)) && (s + (double)(total - consumed)) < 9007199254740992.0;
                 if (lane >= start && !sInt) ok = (s + (double)(incl - consumed)) < next_pow2_above(s);
                 const unsigned long long bad = ~__ballot(ok);
                 if (bad == 0ull) { s = s + (double)(total - consumed); break; }
                 const int f = __ffsll((long long)bad) - 1;
-                const unsigned long long exclF = __shfl(incl - e2, f), inclF = __shfl(incl, f);
-                s = s + (double)(exclF - consumed);
-                uint32_t lo = (base + f) * FILL_NODES_PER_BLOCK, hi = lo + FILL_NODES_PER_BLOCK;
-                if (hi > n) hi = n;
-                s = ctl_walk_block(s, T, P, d, dist, lo, hi, lane);
+                const unsigned long long exclF = __shfl(incl - tot, f), inclF = __shfl(incl, f);
+                s = s + (double)(exclF - consumed);       // exact: still inside the binade
+                s = ctl_partials64(s, be, (cb + (uint32_t)f) * 64u, nblk, T, P, d, dist, n, lane);
                 consumed = inclF;
                 start = f + 1;
             }
