@@ -278,10 +278,10 @@ __global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *
 #define EST_ROUNDS 5        // rounds 0,1 use a 4-wide window, later rounds EST_CAND-wide recentred ones; the last one walks exactly if it must
 #define EST_HEAD 4096
 
-// Segment summaries of one brick: 32 dwords per segment, candidate ci at [ci*4 .. ci*4+3] = (sumS, sumC, A, B).
-// k_est_summ writes a candidate's record with one 16-byte transaction (four lanes), the walking wave reads it
-// with one 16-byte load per lane.
-__device__ __forceinline__ int64_t est_at(int ci, uint32_t seg) { return (int64_t)seg * (4 * EST_CAND) + ci * 4; }
+// Segment summaries of one brick: one plane per candidate, 16 bytes (sumS, sumC, A, B) per segment in it.
+// k_est_summ writes a candidate's record with one 16-byte transaction (four lanes); the walking wave reads 64
+// consecutive segments of its candidate as one contiguous kilobyte.
+#define est_at(ci, seg) (((int64_t)(ci) * summStride + (int64_t)(seg)) * 4)
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
@@ -417,7 +417,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     const int Tbase = c.estTbase;
     uint32_t *out = summ + (int64_t)brick * summStride * (4 * EST_CAND);
     if (__ballot(anyPd != 0) == 0ull) {      // parents reproduce the truths exactly (constant regions): nothing counts
-        if (lane < 4 * nc) out[est_at(0, seg) + lane] = 0;
+        if (lane < 4 * nc) out[est_at(lane >> 2, seg) + (lane & 3)] = 0;
         continue;
     }
 #pragma unroll 1
