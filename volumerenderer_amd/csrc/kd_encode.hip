@@ -320,9 +320,8 @@ __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint
             if (nmask == mask) break;
             mask = nmask;
         }
-        uint32_t v = dec ? (uint32_t)pd : 0u;
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        S += v;
+        // (a DPP scan + readlane: six dependent LDS-crossbar shuffles would cost more than the rest of the step)
+        S += (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(dec ? (uint32_t)pd : 0u), 63);
         C += __popcll(mask);
     }
 }
@@ -651,7 +650,10 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     const uint32_t cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
     *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
     *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
-    const unsigned long long s0 = wave_sum_u64(e0), sm = wave_sum_u64(em), sp = wave_sum_u64(ep);
+    // per-lane sums are < 2^21, a wave's < 2^27: 32-bit DPP scans, the total in lane 63
+    const unsigned long long s0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(e0), 63),
+                             sm = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(em), 63),
+                             sp = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(ep), 63);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         blockErr[(int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = s0;   // 1024 nodes per wave
@@ -1463,13 +1465,9 @@ k_prune_emit12(PruneEmitArgs a)
         for (int jj = 0; jj < 4; ++jj) { mxA = __builtin_elementwise_max(mxA, pk_s(m[jj])); l1p += pk_s(m[jj]); }
     }
     {   // statistics (R.cpp:71-76, 115-129): one record per wave = 1024 leaves
-        int maxErr = max((int)mxB.x, (int)mxB.y), maxAfter = max((int)mxA.x, (int)mxA.y);
-        unsigned long long l1w = (unsigned long long)((int)l1p.x + (int)l1p.y);
-        for (int o = 32; o > 0; o >>= 1) {
-            int u = __shfl_xor(maxErr, o); maxErr = u > maxErr ? u : maxErr;
-            int w = __shfl_xor(maxAfter, o); maxAfter = w > maxAfter ? w : maxAfter;
-            l1w += __shfl_xor(l1w, o);
-        }
+        const int maxErr = wave_max_i32_dpp(max((int)mxB.x, (int)mxB.y)), maxAfter = wave_max_i32_dpp(max((int)mxA.x, (int)mxA.y));
+        const unsigned long long l1w = (uint32_t)__builtin_amdgcn_readlane(
+            (int)wave_incl_scan_add_dpp((uint32_t)((int)l1p.x + (int)l1p.y)), 63);       // < 2^18 per wave
         if ((t & 63) == 0)
             a.blockL1[(int64_t)brick * a.nEmitBlk + (size_t)blk * 4 + (t >> 6)] = stat_pack(l1w, maxErr, maxAfter);
     }
