@@ -289,6 +289,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     return wave_incl_scan_add_dpp(v);      // DPP network: no LDS-crossbar round trips in the serial walks
 }
 
+// value of a wave-uniform lane: v_readlane (a few cycles) instead of an LDS-crossbar shuffle
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int l)
+{
+    return (unsigned long long)lane_u32((uint32_t)v, l) | ((unsigned long long)lane_u32((uint32_t)(v >> 32), l) << 32);
+}
+
 // exact in-order walk of nodes [lo, hi) by one wave; (S,C) are wave-uniform
 __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, uint32_t lo,
                                        uint32_t hi, unsigned long long &S, uint32_t &C, int lane)
@@ -514,14 +521,14 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
         const bool ok = !valid || (S0 - Tc * q >= (long long)A && S0 - (Tc + 1) * q < (long long)B);
         const unsigned long long bad = ~__ballot(ok);
         if (bad == 0ull) {
-            S += __shfl(si, 63);
-            C += __shfl(sci, 63);
+            S += lane_u32(si, 63);
+            C += lane_u32(sci, 63);
             seg += 64;
             continue;
         }
         const int f = __ffsll((long long)bad) - 1;            // first segment whose hypothesis fails
-        S += __shfl(si - ss, f);
-        C += __shfl(sci - sc, f);
+        S += lane_u32(si - ss, f);
+        C += lane_u32(sci - sc, f);
         seg += f;
         est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane);
         Tc = (long long)(S / (2ull * C + 1ull));
@@ -699,7 +706,7 @@ __device__ inline double ctl_walk_block(double s, const uint8_t *__restrict__ T,
             e = (uint32_t)(er * er);
         }
         const uint32_t incl = wave_incl_scan_u32(e, lane);
-        const uint32_t total = __shfl(incl, 63);
+        const uint32_t total = lane_u32(incl, 63);
         uint32_t consumed = 0;
         int start = 0;
         while (true) {
@@ -708,7 +715,7 @@ __device__ inline double ctl_walk_block(double s, const uint8_t *__restrict__ T,
             const unsigned long long bad = ~__ballot(ok);
             if (bad == 0ull) { s = s + (double)(total - consumed); break; }
             const int f = __ffsll((long long)bad) - 1;
-            const uint32_t exclF = __shfl(incl - e, f), eF = __shfl(e, f);
+            const uint32_t exclF = lane_u32(incl - e, f), eF = lane_u32(e, f);
             s = s + (double)(exclF - consumed);   // exact: still inside the binade
             s = s + (double)eF;                   // the reference's rounded add that crosses it
             consumed = exclF + eF;
@@ -779,7 +786,7 @@ __device__ inline double ctl_partials64(double s, const unsigned long long *__re
     // two 32-bit DPP scans (24-bit limbs: 64 partials of < 2^27 each cannot overflow either)
     const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 & 0xFFFFFFull)) +
                                     ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 >> 24)) << 24);
-    const unsigned long long total = __shfl(incl, 63);
+    const unsigned long long total = lane_u64(incl, 63);
     unsigned long long consumed = 0;
     int start = 0;
     while (true) {
@@ -790,7 +797,7 @@ __device__ inline double ctl_partials64(double s, const unsigned long long *__re
         const unsigned long long bad = ~__ballot(ok);
         if (bad == 0ull) { s = s + (double)(total - consumed); break; }
         const int f = __ffsll((long long)bad) - 1;
-        const unsigned long long exclF = __shfl(incl - e2, f), inclF = __shfl(incl, f);
+        const unsigned long long exclF = lane_u64(incl - e2, f), inclF = lane_u64(incl, f);
         s = s + (double)(exclF - consumed);
         uint32_t lo = (base + f) * FILL_NODES_PER_BLOCK, hi = lo + FILL_NODES_PER_BLOCK;
         if (hi > n) hi = n;
@@ -837,7 +844,7 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
             // chunk totals < 2^33: 24-bit low limbs (sum < 2^30) and high limbs < 2^9 (sum < 2^15)
             const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(tot & 0xFFFFFFull)) +
                                             ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(tot >> 24)) << 24);
-            const unsigned long long total = __shfl(incl, 63);
+            const unsigned long long total = lane_u64(incl, 63);
             unsigned long long consumed = 0;
             int start = 0;
             while (true) {
@@ -847,7 +854,7 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
                 const unsigned long long bad = ~__ballot(ok);
                 if (bad == 0ull) { s = s + (double)(total - consumed); break; }
                 const int f = __ffsll((long long)bad) - 1;
-                const unsigned long long exclF = __shfl(incl - tot, f), inclF = __shfl(incl, f);
+                const unsigned long long exclF = lane_u64(incl - tot, f), inclF = lane_u64(incl, f);
                 s = s + (double)(exclF - consumed);       // exact: still inside the binade
                 s = ctl_partials64(s, be, (cb + (uint32_t)f) * 64u, nblk, T, P, d, dist, n, lane);
                 consumed = inclF;
