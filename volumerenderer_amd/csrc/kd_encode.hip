@@ -389,11 +389,13 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     const int brick = blockIdx.y, lane = threadIdx.x & 63;
     const Ctrl &c = ctrls[brick];
     const uint32_t n = 1u << d;
-    if (c.constBrick || c.estDone) return;
+    // one scalar round trip for the control-block fields, in front of the first branch
+    const int cConst = c.constBrick, cDone = c.estDone, cSeg = c.estSeg, cPar = c.par, cTbase = c.estTbase;
+    if (cConst || cDone) return;
     // segments from where the walk stands; later rounds run on a small grid (most bricks are done by then)
     const uint8_t *Tl = temp + (int64_t)brick * heapStride + ((int64_t)1 << d) + lane * 16;
-    const uint8_t *Pl = rb.b[c.par] + (int64_t)brick * leafStride + lane * 8;
-    const uint32_t nseg = n / EST_SEG, seg0 = (uint32_t)c.estSeg + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint8_t *Pl = (cPar == 0 ? rb.b[0] : (cPar == 1 ? rb.b[1] : rb.b[2])) + (int64_t)brick * leafStride + lane * 8;
+    const uint32_t nseg = n / EST_SEG, seg0 = (uint32_t)cSeg + blockIdx.x * 4 + (threadIdx.x >> 6);
     // the next segment's bytes are in flight while this one is summarised (a wave's single load round trip is
     // what bounds this kernel: twice the bytes in flight per wave)
     uint4 tvN = make_uint4(0, 0, 0, 0);
@@ -420,7 +422,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         h[k] = pk_s(T2 ^ (pk_u(nd >> 15) & 0x00FF00FFu));
         anyPd |= pk_u(pd[k]);
     }
-    const int Tbase = c.estTbase;
+    const int Tbase = cTbase;
     uint32_t *out = summ + (int64_t)brick * summStride * (4 * EST_CAND);
     if (__ballot(anyPd != 0) == 0ull) {      // parents reproduce the truths exactly (constant regions): nothing counts
         if (lane < 4 * nc) out[est_at(lane >> 2, seg) + (lane & 3)] = 0;
@@ -618,18 +620,23 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
 {
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
+    // everything the wave needs from the brick's control block is fetched in ONE scalar round trip, before the
+    // first branch (field by field behind branches it was seven dependent ones in front of the data loads)
     Ctrl &c = ctrls[brick];
-    if (c.constBrick || !c.fillThisEpoch) return;
+    const int cConst = c.constBrick, cFill = c.fillThisEpoch, cPar = c.par, cCur = c.cur, cRa = c.ra, cRb = c.rb, cEpoch = c.epoch;
+    const double cDist = c.currentDistance;
+    if (cConst || !cFill) return;
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
     uint8_t *Cd = codes + (int64_t)brick * codeStride + ((int64_t)1 << (d - 2));   // packed: 4 codes per byte
-    const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
-    uint8_t *R = rb.b[phys_buf(c, c.cur)] + (int64_t)brick * leafStride;
-    const int dist = (int)(uint8_t)c.currentDistance;
-    const int distM = (int)(uint8_t)fmax(0.0, c.currentDistance - 1.0);   // R.cpp:334
-    const int distP = (int)(uint8_t)fmin(255.0, c.currentDistance + 1.0);
+    const int rPhys = cCur == 0 ? cRa : cRb;                                         // phys_buf(c, c.cur)
+    const uint8_t *P = (cPar == 0 ? rb.b[0] : (cPar == 1 ? rb.b[1] : rb.b[2])) + (int64_t)brick * leafStride;
+    uint8_t *R = (rPhys == 0 ? rb.b[0] : (rPhys == 1 ? rb.b[1] : rb.b[2])) + (int64_t)brick * leafStride;
+    const int dist = (int)(uint8_t)cDist;
+    const int distM = (int)(uint8_t)fmax(0.0, cDist - 1.0);   // R.cpp:334
+    const int distP = (int)(uint8_t)fmin(255.0, cDist + 1.0);
     // the central difference (R.cpp:333-362) only steers a FOLLOWING epoch: in the last one its result is
     // never read (VolumeKdtree.cpp:333 skips it outright), so the two extra evaluations are not made
-    const bool needDF = c.epoch + 1 < maxEpochs;
+    const bool needDF = cEpoch + 1 < maxEpochs;
     const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
     const uint4 tv = *(const uint4 *)(T + i0);
     const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
@@ -1384,7 +1391,8 @@ k_prune_emit12(PruneEmitArgs a)
     __shared__ uint32_t shw[4];
     const int brick = blockIdx.y, t = threadIdx.x, D = a.D, tol = a.tol;
     Ctrl &c = a.ctrls[brick];
-    if (c.constBrick) return;
+    const int cConst = c.constBrick, cPar = c.par, cRa = c.ra, cRb = c.rb;     // one scalar round trip
+    if (cConst) return;
     const uint32_t blk = blockIdx.x, base = blk << 12;
     uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     // ---- every global load of the block, in one batch
@@ -1399,7 +1407,7 @@ k_prune_emit12(PruneEmitArgs a)
     const int64_t li = ((int64_t)1 << D) + base + t * 16;
     const uint32_t cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
     const uint4 tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
-    const uint4 rv = *(const uint4 *)(a.rb.b[c.par] + (int64_t)brick * a.leafStride + base + t * 16);
+    const uint4 rv = *(const uint4 *)((cPar == 0 ? a.rb.b[0] : (cPar == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
     lutS[t] = lutV;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
     for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
@@ -1604,7 +1612,7 @@ k_prune_emit12(PruneEmitArgs a)
         a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + (t >> 2)] = aliveAtDs ? pos + (uint32_t)preDs : VR_IDX_DEAD;
     __syncthreads();
     const uint32_t nw = (tot + 15u) >> 4;
-    const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk);
+    const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
     for (uint32_t i = t; i < nw; i += 256) *pe_stage(stg, i) = W[i];
 }
 
