@@ -351,3 +351,54 @@ def test_estimator_threshold_drift(vr, oracle, seed):
     for tol, ep in ((1, 2), (4, 5)):
         check_case(vr, oracle, vol, tol, ep)
     check_case(vr, oracle, np.ascontiguousarray(vol.transpose(2, 1, 0)), 1, 2)
+
+
+def _fuzz_volume(rng, shape, kind):
+    z, y, x = shape
+    if kind == 0:
+        return rng.integers(0, 256, shape, dtype=np.uint8)
+    if kind == 1:
+        zz, yy, xx = np.meshgrid(np.arange(z), np.arange(y), np.arange(x), indexing="ij")
+        v = (128 + 100 * np.sin(xx * rng.uniform(0.05, 0.6)) * np.cos(yy * rng.uniform(0.05, 0.6)) + zz * rng.uniform(-2, 2)
+             + rng.integers(0, rng.integers(1, 6), shape))
+        return np.clip(v, 0, 255).astype(np.uint8)
+    if kind == 2:     # piecewise constant boxes with noisy patches
+        v = np.full(shape, int(rng.integers(0, 256)), np.int64)
+        for _ in range(rng.integers(1, 6)):
+            a = [sorted(rng.integers(0, s + 1, 2)) for s in shape]
+            v[a[0][0]:a[0][1], a[1][0]:a[1][1], a[2][0]:a[2][1]] = rng.integers(0, 256)
+        for _ in range(rng.integers(0, 3)):
+            a = [sorted(rng.integers(0, s + 1, 2)) for s in shape]
+            sub = v[a[0][0]:a[0][1], a[1][0]:a[1][1], a[2][0]:a[2][1]]
+            sub += rng.integers(-rng.integers(1, 40), 40, sub.shape)
+        return np.clip(v, 0, 255).astype(np.uint8)
+    if kind == 3:     # saturated ends with noise: the clamps at 0 / 255 matter
+        v = np.where(rng.random(shape) < 0.5, rng.integers(0, 12, shape), rng.integers(244, 256, shape))
+        return np.where(rng.random(shape) < 0.2, rng.integers(0, 256, shape), v).astype(np.uint8)
+    return np.full(shape, int(rng.integers(0, 256)), np.uint8)
+
+
+def test_randomized_parity(vr, oracle):
+    """Seeded fuzz over shapes (both sides of the 12-level kernels), data kinds, tolerance, epochs and variant;
+    scratch/fuzz.py is the same loop with thousands of cases (4400 run clean on an MI355X)."""
+    shapes = [(16, 16, 16), (32, 16, 32), (32, 32, 32), (16, 32, 64), (64, 32, 16), (64, 64, 64), (8, 8, 8), (4, 32, 2), (64, 64, 32)]
+    rng = np.random.default_rng(2026)
+    for _ in range(120):
+        shape = shapes[rng.integers(0, len(shapes))]
+        kind, tol = int(rng.integers(0, 5)), int(rng.choice([0, 1, 1, 2, 5, 9]))
+        ep, var = int(rng.choice([1, 2, 2, 3, 5])), int(rng.choice([0, 0, 1]))
+        vol = _fuzz_volume(rng, shape, kind)
+        z, y, x = shape
+        ref = oracle.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep, guarded=bool(var)).build()
+        bs = vr.BrickSet(1, (x, y, z), tol, ep, var)
+        bs.build(vol.copy())
+        info, st, what = bs.info(0), ref.leaf_stats(), (shape, kind, tol, ep, var)
+        assert info["num_active_nodes"] == ref.numActiveNodes, what
+        assert list(bs.distance_map(0)) == list(ref.distanceMap), what
+        assert np.array_equal(bs.tree(0), ref.tree), what
+        assert info["num_reverts"] == ref.numReverts, what
+        assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"], what
+        assert np.array_equal(bs.decode().cpu().numpy().reshape(shape), ref.levelCut()), what
+        if ref.origTreeDepth >= 8:
+            cut = int(rng.integers(2, ref.origTreeDepth))
+            assert np.array_equal(bs.decode(cut_depth=cut).cpu().numpy().reshape(shape), ref.levelCutProgressive(cut)), what
