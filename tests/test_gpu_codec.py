@@ -402,3 +402,22 @@ def test_randomized_parity(vr, oracle):
         if ref.origTreeDepth >= 8:
             cut = int(rng.integers(2, ref.origTreeDepth))
             assert np.array_equal(bs.decode(cut_depth=cut).cpu().numpy().reshape(shape), ref.levelCutProgressive(cut)), what
+
+
+def test_reopened_file_decodes_through_the_tile_kernel(vr, oracle, tmp_path):
+    """A brick wide enough for k_decode_tile (X >= 128), saved, reopened (side-car index rebuilt on the host from
+    the bytes alone) and decoded: equal to the oracle and to the decode of the tree that was built in place."""
+    shape = (16, 32, 128)
+    vol = rm_like(shape)
+    t = vr.VolumeKdtree(vol.copy(), 128, 32, 16)
+    t.setMaxEpochs(2); t.setErrorTolerance(1)
+    t.build()
+    want = t.levelCut().cpu().numpy().copy()
+    p = str(tmp_path / "wide.bin")
+    t.save(p)
+    u = vr.VolumeKdtree().open(p)
+    got = u.levelCut(u.maxTreeDepth).cpu().numpy()
+    ref = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=2).build()
+    assert np.array_equal(got, want) and np.array_equal(got.reshape(shape), ref.levelCut())
+    cut = u.levelCut(9).cpu().numpy()          # progressive cut above the index level, foreign stream
+    assert np.array_equal(cut.reshape(shape), ref.levelCutProgressive(9))
