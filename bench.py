@@ -118,9 +118,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--groups", type=int, default=1, help="pipeline 2: independent brick groups (streams) per step")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
-                    help="2 (default): two bricksets on two HIP streams, levelCut of step k overlaps build of step k+1 "
-                         "(the streaming use: the next timestep compresses while this one decodes); 1: strictly serial")
+    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
+                    help="bricksets in flight.  3 (default, ~65 GB each of the 288 GB): two build streams and a decode "
+                         "stream -- the levelCut of step k and the build of step k+1 run beside the build of step k+2 "
+                         "(the streaming use: the next timesteps compress while this one decodes; falls back to 2 if "
+                         "the third set does not fit); 2: one build stream and one decode stream; 1: strictly serial")
     ap.add_argument("--composite", action="store_true",
                     help="N > 1 only: also time a sort-last composited 1080p frame over RCCL (off by default: a "
                          "collective that fails on one rank must never hang the headline measurement)")
@@ -162,43 +164,61 @@ def main():
     vox = vox4.reshape(-1)                                      # inputs resident in HBM before timing
     out = torch.empty_like(vox)
     bs = vr.BrickSet(B, bdims, args.tolerance, args.max_epochs)
-    # pipeline == 2: the bricks are dealt to `groups` independent brickset pairs, each with its own build and
-    # decode stream, so one group's serial per-level kernels (one wave per brick) run beside another group's
-    # bandwidth-bound ones and every decode runs beside later builds
-    G = max(1, min(args.groups, B)) if args.pipeline == 2 else 1
+    # pipeline >= 2: several bricksets in flight (see run_steps).  `groups` > 1 additionally deals the bricks to
+    # independent brickset groups with their own streams (measured: no gain, default 1).
+    G = max(1, min(args.groups, B)) if args.pipeline >= 2 else 1
     cuts = [B * g // G for g in range(G + 1)]
-    gsets = [[vr.BrickSet(cuts[g + 1] - cuts[g], bdims, args.tolerance, args.max_epochs) for _ in range(2)]
-             for g in range(G)] if args.pipeline == 2 else []
     gvox = [vox[cuts[g] * V:cuts[g + 1] * V] for g in range(G)]
     gout = [out[cuts[g] * V:cuts[g + 1] * V] for g in range(G)]
-    s_build = [torch.cuda.Stream() for _ in range(G)]
+    NS = args.pipeline                 # bricksets per group
+    gsets = []
+    if NS >= 2:
+        try:
+            gsets = [[vr.BrickSet(cuts[g + 1] - cuts[g], bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
+                     for g in range(G)]
+            for g in range(G):         # setup, not a step: allocate and first-touch every set's buffers
+                for s_ in gsets[g]:
+                    s_.build(gvox[g]); s_.decode(gout[g])
+            torch.cuda.synchronize()
+        except vr.VrError:             # out of device memory: one set less
+            if NS == 2:
+                raise
+            gsets = []
+            torch.cuda.synchronize()
+            NS = 2
+            gsets = [[vr.BrickSet(cuts[g + 1] - cuts[g], bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
+                     for g in range(G)]
+            for g in range(G):
+                for s_ in gsets[g]:
+                    s_.build(gvox[g]); s_.decode(gout[g])
+            torch.cuda.synchronize()
+    NB = max(1, NS - 1)                # build streams per group
+    s_build = [[torch.cuda.Stream() for _ in range(NB)] for _ in range(G)]
     s_dec = [torch.cuda.Stream() for _ in range(G)]
 
     def run_steps(n):
         """n x (build + levelCut) of the whole volume; every launch of every step is inside the caller's timed
-        region.  pipeline == 2: brickset k%2 is built on one stream and decoded on the other, so the decode of
-        step k runs beside the build of step k+1; a brickset is rebuilt only after its decode has finished."""
-        if args.pipeline == 1:
+        region.  With NS >= 2 bricksets, step k uses set k % NS: its build goes to build stream k % (NS - 1), its
+        levelCut to the decode stream, so a decode runs beside the build(s) of the following step(s); a brickset is
+        rebuilt only after its decode has finished."""
+        if NS == 1:
             for _ in range(n):
                 bs.build(vox)
                 bs.decode(out)
             return
-        decoded = [[None, None] for _ in range(G)]
+        decoded = [[None] * NS for _ in range(G)]
         for k in range(n):
-            i = k % 2
+            i = k % NS
             for g in range(G):
+                sb = s_build[g][k % NB]
                 if decoded[g][i] is not None:
-                    s_build[g].wait_event(decoded[g][i])
-                gsets[g][i].build(gvox[g], stream=s_build[g])
-                built = torch.cuda.Event(); built.record(s_build[g])
+                    sb.wait_event(decoded[g][i])
+                gsets[g][i].build(gvox[g], stream=sb)
+                built = torch.cuda.Event(); built.record(sb)
                 s_dec[g].wait_event(built)
                 gsets[g][i].decode(gout[g], stream=s_dec[g])
                 decoded[g][i] = torch.cuda.Event(); decoded[g][i].record(s_dec[g])
 
-    if args.pipeline == 2:          # setup, not a step: first touch of the second brickset's buffers
-        for g in range(G):
-            gsets[g][1].build(gvox[g]); gsets[g][1].decode(gout[g])
-        torch.cuda.synchronize()
     run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -262,9 +282,8 @@ def main():
                       "maxEpochs %d, VolumeKdtree build + levelCut" % (gdims[0], gdims[1], gdims[2], B, bdims[0],
                                                                          bdims[1], bdims[2], args.kind, args.tolerance,
                                                                          args.max_epochs),
-                      "pipeline": ("%d brick groups x 2 bricksets on %d HIP streams: levelCut of step k overlaps build of "
-                                   "step k+1, one group's serial per-level kernels overlap another's bulk ones"
-                                   % (G, 2 * G) if args.pipeline == 2 else "serial"),
+                      "pipeline": ("%d bricksets in flight on %d build stream(s) + 1 decode stream: levelCut of step k "
+                                   "overlaps the builds of the following steps" % (NS, NB) if NS >= 2 else "serial"),
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
