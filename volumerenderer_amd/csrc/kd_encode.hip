@@ -1016,8 +1016,9 @@ k_prune_level(int d, const Ctrl *ctrls, uint8_t *__restrict__ codes, uint8_t *__
 // distances 64, 32, .., 1 until the error is within tolerance) depends only on the initial error
 // m0 = |truth - recon| and the side, as long as the clamps at 0 / 255 cannot matter: a clamped step
 // lands min(truth, 255 - truth) away from the truth, which is never an improvement while that is
-// >= the current error.  lut[m0] = tokens (2 bits each, "add" = towards the truth first) | count << 14
-// | final error << 20; the other side swaps add <-> sub.  Leaves with m0 > min(t, 255 - t) take
+// >= the current error.  lut[m0] = final error | count << 8 | tokens << 16 (2 bits each, "add" = towards the truth
+// first; byte-aligned so that two entries fold into packed lanes with one v_perm each); the other side swaps
+// add <-> sub.  Leaves with m0 > min(t, 255 - t) take
 // the exact step-by-step path.
 __global__ void k_chain_lut(int tol, int nsteps, uint32_t *__restrict__ lut)
 {
@@ -1030,7 +1031,7 @@ __global__ void k_chain_lut(int tol, int nsteps, uint32_t *__restrict__ lut)
         else { bits |= 3u << (2 * n); ++n; break; }
     }
     const int fe = rec > t ? rec - t : t - rec;
-    lut[m0] = bits | (n << 14) | ((uint32_t)fe << 20);
+    lut[m0] = (uint32_t)fe | (n << 8) | (bits << 16);     // byte 0: final error, byte 1: token count, bytes 2-3: tokens
 }
 __device__ __forceinline__ uint32_t chain_mirror(uint32_t ch) { return ch ^ (((ch ^ (ch >> 1)) & 0x1555u) * 3u); }   // add <-> sub
 
@@ -1110,8 +1111,8 @@ k_prune12(int D, int tol, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t
         const uint32_t viol = pk_u((lim - mm) >> 15);
         const uint32_t e0 = lutS[m[j] & 255u], e1 = lutS[(m[j] >> 16) & 255u];
         const uint32_t useL = ~pruned & ~viol;
-        nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
-        m[j] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[j]);
+        nt[j] = 0x00010001u + (useL & __builtin_amdgcn_perm(e1, e0, 0x0c050c01u));                // the two counts
+        m[j] = (useL & __builtin_amdgcn_perm(e1, e0, 0x0c040c00u)) | (~useL & m[j]);               // the two final errors
         act[j] = ~pruned & viol;
         anyAct |= act[j];
     }
@@ -1444,11 +1445,11 @@ k_prune_emit12(PruneEmitArgs a)
             const uint32_t viol = pk_u((lim - mm) >> 15);                                          // a clamp could matter
             const uint32_t e0 = lutS[m[jj] & 255u], e1 = lutS[(m[jj] >> 16) & 255u];
             const uint32_t useL = ~pruned & ~viol;
-            const uint32_t ch2 = (e0 & 0x3FFFu) | ((e1 & 0x3FFFu) << 16);
+            const uint32_t ch2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);                           // the two token strings
             const uint32_t mir = ch2 ^ (((ch2 ^ (ch2 >> 1)) & 0x15551555u) * 3u);                   // add <-> sub
             Lb[j] = lcode | ((useL & ((sg[jj] & mir) | (~sg[jj] & ch2))) << 2);
-            nt[j] = 0x00010001u + (useL & (((e0 >> 14) & 7u) | (((e1 >> 14) & 7u) << 16)));
-            m[jj] = (useL & (((e0 >> 20) & 255u) | (((e1 >> 20) & 255u) << 16))) | (~useL & m[jj]);
+            nt[j] = 0x00010001u + (useL & __builtin_amdgcn_perm(e1, e0, 0x0c050c01u));            // the two counts
+            m[jj] = (useL & __builtin_amdgcn_perm(e1, e0, 0x0c040c00u)) | (~useL & m[jj]);         // the two final errors
             act[jj] = ~pruned & viol;
             anyAct |= act[jj];
         }
@@ -1855,9 +1856,9 @@ __device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const
                         const int m0 = rec > t ? rec - t : t - rec, lim = t < 255 - t ? t : 255 - t;
                         if (m0 <= lim) {                                     // no clamp can matter: table (see k_chain_lut)
                             const uint32_t en = lutS[m0];
-                            const uint32_t ch = en & 0x3FFFu;
+                            const uint32_t ch = en >> 16;
                             bits |= (t > rec ? ch : chain_mirror(ch)) << 2;
-                            nt += (int)((en >> 14) & 7u);
+                            nt += (int)((en >> 8) & 7u);
                         } else {
                             int depth = D;
                             while (depth < maxDepth) {
