@@ -42,6 +42,8 @@ struct BrickSet {
     uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)
     uint8_t *idxVal = nullptr;  // B * nIdx  decoded scalar of that root (or of the pruned ancestor)
     uint8_t *idxValCut = nullptr; // B * nIdx  progressive cut above the index level: ancestor scalars
+    uint8_t *fineIdx = nullptr;   // B * nIdx * 16  tokens owned by each 4-leaf subtree of a depth-Ds node (fused encoder only)
+    bool fineValid = false;       // fineIdx describes the current stream
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
     bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream

@@ -134,8 +134,9 @@ k_decode_lane(DecodeArgs a)
 //           grown-branch step, or 4 voxels of a pruned node's fill.  A branch step skips
 //           a run of "keep" codes with one ctz and swallows a following terminator, and
 //           a leaf swallows an immediate terminator, so a voxel costs ~3 iterations
-//           instead of one per token.  Leaves are emitted in stream (Morton) order as
-//           bytes into an LDS tile [leaf][lane];
+//           instead of one per token.  Leaves are emitted in stream (Morton) order into an
+//           LDS tile of words [leaf / 4][lane] (bank = lane); a pruned pair or quad of voxels
+//           costs no extra iteration, larger pruned nodes are filled 8 voxels at a time;
 //   gather  the wave re-reads the tile as 16-byte row pieces and stores 8 full 128-byte
 //           lines per instruction.
 // Requirements: the six deepest split levels cycle through x,y,z twice (any order) and
@@ -155,10 +156,10 @@ struct TileArgs {
     int cut;                    // progressive cut depth (maxTreeDepth = the reference's levelCut)
     const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
     const uint32_t *spread;     // BrickSet::spread (coordinate -> Morton rank bits)
+    const uint8_t *fine;        // BrickSet::fineIdx (k_decode_fine only)
 };
 
 #define DEC_WAVES 4
-#define DEC_DUMMY_ROW 64
 #define DEC_SW 19            // staged words per lane (usable lookahead: DEC_SW-2 words per stage); 19 = four blocks per CU in LDS (40 480 B each)
 
 __device__ __forceinline__ int med3i(int x, int lo, int hi)
@@ -175,10 +176,64 @@ __device__ __forceinline__ int clamp_add(int pv, int tok, int dist)
     return nv < 0 ? 0 : (nv > 255 ? 255 : nv);
 }
 
+// grown-branch tables (256 threads): compose v -> min(max(v + A, LO), HI) over steps first..first+n-1 (distances
+// dmS[8 + step]), stop at a terminator (code 3).  Table 1: branch tokens 1-4 (256 entries), table 2: 5-7 (64).
+// Entry: [0:10) A + 256, [10:18) LO, [18:26) HI, [26:29) tokens consumed, 29 a terminator ended it.
+__device__ __forceinline__ void chain_tables(const uint8_t *dmS, uint32_t *lutC1, uint32_t *lutC2)
+{
+    const int idx = threadIdx.x;
+    for (int tb = 0; tb < 2; ++tb) {
+        const int first = tb == 0 ? 1 : 5, n = tb == 0 ? 4 : 3;
+        if (tb == 1 && idx >= 64) break;
+        int A = 0, LO = 0, HI = 255, len = 0, term = 0;
+        for (int q = 0; q < n; ++q) {
+            const int tok = (idx >> (2 * q)) & 3;
+            ++len;
+            if (tok == 3) { term = 1; break; }
+            const int dist = dmS[8 + first + q];
+            const int dl = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+            A += dl;
+            LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
+            HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
+        }
+        const uint32_t ent = (uint32_t)(A + 256) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) |
+                             ((uint32_t)term << 29);
+        if (tb == 0) lutC1[idx] = ent; else lutC2[idx] = ent;
+    }
+}
+
+// the wave re-reads its LDS tile (words [leaf / 4][subtree], `stride` words per row) as 16-byte row pieces
+// and stores whole 128-byte lines of the output volume
+__device__ __forceinline__ void tile_gather(const TileArgs &a, const uint32_t *tile, int stride, int live, int brick,
+                                            int tx, int ty, int tz, int lane)
+{
+    const int jx = a.jx, jy = a.jy, jz = a.jz;
+    const int c = lane & 7;
+    uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16;
+    const auto tile_at = [stride](int rank) { return (rank >> 2) * (4 * stride) + (rank & 3); };   // byte of a leaf within a column
+    const int r1 = live * tile_at(1 << jx), r2 = live * tile_at(8 << jx);             // steps of dx bit 0 / bit 1
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int R = st * 8 + (lane >> 3);
+        const int y = R & 7, z = R >> 3;
+        const int dy = y & 3, dz = z & 3;
+        const int rb = ((dy & 1) << jy) | ((dy >> 1) << (3 + jy)) | ((dz & 1) << jz) | ((dz >> 1) << (3 + jz));
+        const uint8_t *src = (const uint8_t *)tile + tile_at(rb) * live + 4 * (4 * c + 32 * (y >> 2));
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint8_t *sk = src + 4 * k;
+            o[k] = (uint32_t)sk[0] | ((uint32_t)sk[r1] << 8) | ((uint32_t)sk[r2] << 16) | ((uint32_t)sk[r1 + r2] << 24);
+        }
+        const int64_t gy = (int64_t)ty * 8 + y, gz = (int64_t)tz * 4 + z;
+        *(uint4 *)(O + (int64_t)a.g.X * (gy + (int64_t)a.g.Y * gz)) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ void __launch_bounds__(64 * DEC_WAVES)
 k_decode_tile(TileArgs a)
 {
-    __shared__ uint8_t tileS[DEC_WAVES][65 * 64];      // [leaf][lane]; row 64 = scratch for predicated-off writes
+    __shared__ uint32_t tileS[DEC_WAVES][16 * 64];     // [leaf / 4][lane], four consecutive leaves (Morton ranks) per word
     __shared__ uint32_t strS[DEC_WAVES][DEC_SW * 64];   // [word][lane]
     __shared__ uint8_t stkS[DEC_WAVES][8 * 64];         // [level][lane]
     __shared__ uint8_t dmS[16];      // [1..6] tree levels Ds+1..D, [9..15] grown-branch levels D+1..D+7
@@ -188,7 +243,7 @@ k_decode_tile(TileArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * DEC_WAVES + wave;
-    uint8_t *tile = tileS[wave];
+    uint32_t *tile = tileS[wave];
     uint32_t *str = strS[wave];
     uint8_t *stk = stkS[wave];
     const bool tileValid = tileId < a.tilesX * a.tilesY * a.tilesZ;
@@ -207,7 +262,8 @@ k_decode_tile(TileArgs a)
         //   [0:9) delta of the node + 256   [9:18) delta of the left child + 256 (256 = none)
         //   18 second (left child handled)  [19:21) descents (0: node terminal, 1: child terminal -> continue at the
         //   node's right child, 2: continue at the child's left child)  21 lf (a voxel leaf with a branch behind it)
-        //   22 single (one voxel to emit)   [23:30) fill count of a pruned node   30 terminal   31 valid
+        //   [22:25) voxels the step emits at once: a voxel leaf (1) or a pruned pair / quad (2, 4)
+        //   [25:29) size / 8 of a larger pruned node (filled 8 voxels per iteration)   30 terminal   31 valid
         // second word, what the step would otherwise derive with compares: [0:10) byte offset of the value-stack
         // row the node's value goes to (scratch row 6 when it does not descend), [10:20) same for the child,
         // [20:23) bits of tree tokens consumed, [23:25) path shift, 25 path "or 1" (continue at the right child)
@@ -231,37 +287,17 @@ k_decode_tile(TileArgs a)
                 fillc = (is31 && !leaf1) ? (64 >> (j + 1)) : 0;
                 single = leaf1 ? 1 : 0;
             }
+            const int size = single ? 1 : fillc;
             ent = (uint32_t)(delta(t0, j) + 256) | ((uint32_t)(d1 + 256) << 9) | ((uint32_t)second << 18) | ((uint32_t)ndesc << 19) |
-                  ((uint32_t)lf << 21) | ((uint32_t)single << 22) | ((uint32_t)fillc << 23) | ((ndesc < 2 ? 1u : 0u) << 30) | (1u << 31);
+                  ((uint32_t)lf << 21) | ((uint32_t)(size <= 4 ? size : 0) << 22) | ((uint32_t)(size >= 8 ? size >> 3 : 0) << 25) |
+                  ((ndesc < 2 ? 1u : 0u) << 30) | (1u << 31);
             ent2 = (uint32_t)((ndesc >= 1 ? j : 6) * 64) | ((uint32_t)((ndesc == 2 ? j + 1 : 6) * 64) << 10) |
                    ((uint32_t)(2 + 2 * second) << 20) | ((uint32_t)ndesc << 23) | ((ndesc == 1 ? 1u : 0u) << 25);
         }
         lutP[key] = ent;
         lutP[129 + key] = ent2;
     }
-    {
-        // grown-branch tables: compose v -> min(max(v + A, LO), HI) over steps first..first+n-1
-        // (distances dmS[8 + step]); stop at a terminator (code 3).
-        const int idx = threadIdx.x;                      // 256 threads: table 1 has 256 entries, table 2 uses 64
-        for (int tb = 0; tb < 2; ++tb) {
-            const int first = tb == 0 ? 1 : 5, n = tb == 0 ? 4 : 3;
-            if (tb == 1 && idx >= 64) break;
-            int A = 0, LO = 0, HI = 255, len = 0, term = 0;
-            for (int q = 0; q < n; ++q) {
-                const int tok = (idx >> (2 * q)) & 3;
-                ++len;
-                if (tok == 3) { term = 1; break; }
-                const int dist = dmS[8 + first + q];
-                const int dl = tok == 1 ? dist : (tok == 2 ? -dist : 0);
-                A += dl;
-                LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
-                HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
-            }
-            const uint32_t ent = (uint32_t)(A + 256) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) |
-                                 ((uint32_t)term << 29);
-            if (tb == 0) lutC1[idx] = ent; else lutC2[idx] = ent;
-        }
-    }
+    chain_tables(dmS, lutC1, lutC2);
     __syncthreads();
     if (!tileValid) return;
     const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
@@ -275,7 +311,7 @@ k_decode_tile(TileArgs a)
     // a tile whose 64 subtrees all lie under pruned nodes (constant regions) needs no walk: one value per
     // subtree goes to tile row 0 and the gather below reads every leaf from there
     const bool waveDead = __ballot(off != VR_IDX_DEAD) == 0ull;
-    if (waveDead) tile[lane] = (uint8_t)val0;
+    if (waveDead) tile[lane] = (uint32_t)val0 * 0x01010101u;
     else {
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
         const bool dead = off == VR_IDX_DEAD;
@@ -286,6 +322,7 @@ k_decode_tile(TileArgs a)
         int v = val0;
         int fill = dead ? 64 : 0;       // voxels of a pruned node still to write
         int leaf = 0;                   // next leaf (Morton rank) to emit
+        uint32_t cur = 0;               // the tile word under construction (leaves 4 * (leaf / 4) ..)
         if (dead) p = 0x80000000u;
         // value stack rows 0..5 = pushed ancestors, row 6 = scratch for predicated-off pushes,
         // row 7 = the root's "parent" (the index value itself; dmS[0] = 0 leaves it unchanged)
@@ -308,14 +345,14 @@ k_decode_tile(TileArgs a)
                 const bool act = !done && (bitpos >> 5) < DEC_SW - 2;
                 if (__ballot(act) == 0ull) break;
                 const bool filling = act && fill > 0;
-                if (__ballot(filling) != 0ull) {            // wave-uniform: skipped when nobody fills
-                    const int n4 = filling ? (fill < 4 ? fill : 4) : 0;
-                    uint8_t *t4 = tile + lane;
-                    const uint8_t fv = (uint8_t)v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) t4[(i < n4 ? leaf + i : DEC_DUMMY_ROW) * 64] = fv;
-                    leaf += n4; fill -= n4;
-                    done = done || (filling && fill == 0 && p == 0x80000000u);
+                if (__ballot(filling) != 0ull) {            // wave-uniform: only pruned nodes of 8+ voxels come here
+                    if (filling) {
+                        uint32_t *t8 = tile + (leaf >> 2) * 64 + lane;
+                        cur = (uint32_t)v * 0x01010101u;
+                        t8[0] = cur; t8[64] = cur;
+                        leaf += 8; fill -= 8;
+                        done = done || (fill == 0 && p == 0x80000000u);
+                    }
                 }
                 const bool tk = act && !filling;                    // this lane consumes tokens now
                 const uint32_t k = bitpos >> 5;
@@ -341,14 +378,18 @@ k_decode_tile(TileArgs a)
                 const uint32_t clen = ((e1 >> 26) & 7u) + (more ? ((e2 >> 26) & 7u) : 0u);
                 const int vo = lf ? (more ? b2 : b1) : vb;
                 const bool t = ((e >> 30) & 1u) != 0u;
-                const uint32_t single = (e >> 22) & 1u;
-                const uint32_t fillc = (e >> 23) & 127u;
+                const uint32_t ne = (e >> 22) & 7u;                              // 0, 1, 2 or 4 voxels emitted here
+                const uint32_t fillc = (e >> 22) & 0x78u;                         // 8 * bits [25:29)
                 v = tk ? vo : v;
                 stk[(f & 1023u) + lane] = (uint8_t)nv;
                 stk[((f >> 10) & 1023u) + lane] = (uint8_t)nv1;
                 bitpos += ((f >> 20) & 7u) + (lf ? 2u * clen : 0u);
-                tile[(single ? leaf : DEC_DUMMY_ROW) * 64 + lane] = (uint8_t)vo;
-                leaf += (int)single;
+                // the voxels go into the word under construction, which is (re)written every step: an unfinished or
+                // stale word is harmless, the step that completes a word writes all four of its bytes
+                const uint32_t em = ((1u << ((ne * 8u) & 31u)) - 1u) << (((uint32_t)leaf & 3u) * 8u) | (uint32_t)((int32_t)(e << 7) >> 31);
+                cur = (((uint32_t)vo * 0x01010101u) & em) | (cur & ~em);
+                tile[min(leaf >> 2, 15) * 64 + lane] = cur;
+                leaf += (int)ne;
                 fill = fillc ? (int)fillc : fill;
                 uint32_t np = p + 1u;
                 np >>= (__ffs((int)np) - 1);
@@ -362,29 +403,157 @@ k_decode_tile(TileArgs a)
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): my LDS writes have landed
     __builtin_amdgcn_wave_barrier();
 
-    // ---- gather 16-byte row pieces and store whole 128-byte lines
-    const int jx = a.jx, jy = a.jy, jz = a.jz;
-    const int c = lane & 7;
-    uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16;
-    const int live = waveDead ? 0 : 1;
-    const int r1 = live << jx, r2 = (8 * live) << jx;            // Morton rank steps of dx bit 0 / bit 1
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int R = st * 8 + (lane >> 3);
-        const int y = R & 7, z = R >> 3;
-        const int dy = y & 3, dz = z & 3;
-        const int rb = ((dy & 1) << jy) | ((dy >> 1) << (3 + jy)) | ((dz & 1) << jz) | ((dz >> 1) << (3 + jz));
-        const uint8_t *src = tile + rb * live * 64 + 4 * c + 32 * (y >> 2);
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint8_t *sk = src + k;
-            o[k] = (uint32_t)sk[0] | ((uint32_t)sk[r1 * 64] << 8) | ((uint32_t)sk[r2 * 64] << 16) |
-                   ((uint32_t)sk[(r1 + r2) * 64] << 24);
-        }
-        const int64_t gy = (int64_t)ty * 8 + y, gz = (int64_t)tz * 4 + z;
-        *(uint4 *)(O + (int64_t)a.g.X * (gy + (int64_t)a.g.Y * gz)) = make_uint4(o[0], o[1], o[2], o[3]);
+    tile_gather(a, tile, 64, waveDead ? 0 : 1, brick, tx, ty, tz, lane);
+}
+
+// ---- fine tile decode -----------------------------------------------------------------
+// Same tile, same gather, but ONE LANE PER FOUR VOXELS and no walk: the fused encoder leaves, next to the
+// depth-Ds index, how many tokens every 4-leaf subtree owns in preorder (its 7 nodes, their grown branches, and
+// the ancestors down from depth Ds whose first leaf is its first leaf).  A DPP row (16 lanes) takes one depth-Ds
+// subtree: a row prefix sum of the counts gives every lane its token offset, the owned ancestors are resolved
+// top-down in four steps (owner decodes, ds_swizzle / quad_perm broadcast value + "pruned" to the lanes below),
+// and then each lane decodes its own 7 nodes as straight-line predicated code -- at most 43 tokens, held in four
+// registers staged through LDS for the bit-addressed lookahead.  16 such steps fill the wave's 64-subtree tile.
+#define FD_WAVES 4
+#define FD_TS 68          // tile row stride in words: lanes (g, S) -> bank 4g + S, conflict-free
+
+struct LeafOut { int v; uint32_t bits; };
+
+// one voxel leaf: its code at the low end of `y`, then its grown branch (R.cpp:655-704 as the decoder sees it)
+__device__ __forceinline__ LeafOut fine_leaf(uint32_t y, bool own, int vp, int d6, const uint32_t *lutC1, const uint32_t *lutC2)
+{
+    const uint32_t tok = own ? (y & 3u) : 0u;
+    const int vl = clamp_add(vp, (int)tok, d6);
+    const bool lf = own && tok != 3u;
+    const uint32_t xc = y >> 2;
+    const uint32_t e1 = lutC1[xc & 255u], e2 = lutC2[(xc >> 8) & 63u];
+    const int b1 = med3i(vl + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
+    const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
+    const bool more = ((e1 >> 29) & 1u) == 0u;
+    const uint32_t clen = ((e1 >> 26) & 7u) + (more ? ((e2 >> 26) & 7u) : 0u);
+    LeafOut o;
+    o.v = lf ? (more ? b2 : b1) : vl;
+    o.bits = own ? 2u + (lf ? 2u * clen : 0u) : 0u;
+    return o;
+}
+
+__global__ void __launch_bounds__(64 * FD_WAVES)
+k_decode_fine(TileArgs a)
+{
+    __shared__ uint32_t tileS[FD_WAVES][16 * FD_TS];    // [leaf / 4][subtree]
+    __shared__ uint32_t strS[FD_WAVES][5 * 64];         // [word][lane]: my 4 stream words (+ 1 never needed but read)
+    __shared__ uint32_t offS[FD_WAVES][64];             // per subtree of the tile: token offset of its root
+    __shared__ uint32_t cntS[FD_WAVES][64 * 4];         // ... the 16 owned-token counts (bytes)
+    __shared__ uint8_t valS[FD_WAVES][64];              // ... the scalar its root starts from
+    __shared__ uint8_t dmS[16];
+    __shared__ uint32_t lutC1[256], lutC2[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int brick = blockIdx.y;
+    const int tileId = blockIdx.x * FD_WAVES + wave;
+    uint32_t *tile = tileS[wave];
+    uint32_t *str = strS[wave];
+    const bool tileValid = tileId < a.tilesX * a.tilesY * a.tilesZ;
+    if (threadIdx.x < 16) {
+        const uint8_t *dmap = a.ctrls[brick].distanceMap;
+        const int t = threadIdx.x;
+        const int depth = t < 8 ? a.Ds + (t < 7 ? t : 0) : a.D + (t - 8);
+        dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];      // as in k_decode_tile
     }
+    __syncthreads();
+    chain_tables(dmS, lutC1, lutC2);
+    __syncthreads();
+    if (!tileValid) return;
+    const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
+    const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
+    const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
+    const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
+    const int val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
+    const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
+    if (liveMask == 0ull) tile[lane] = (uint32_t)val0 * 0x01010101u;      // as in k_decode_tile
+    else {
+        uint4 cv = make_uint4(0, 0, 0, 0);
+        if (off != VR_IDX_DEAD) cv = *(const uint4 *)(a.fine + ((int64_t)brick * a.nIdx + s) * 16);
+        offS[wave][lane] = off;
+        valS[wave][lane] = (uint8_t)val0;
+        *(uint4 *)&cntS[wave][lane * 4] = cv;
+        const int d1 = dmS[1], d2 = dmS[2], d3 = dmS[3], d4 = dmS[4], d5 = dmS[5], d6 = dmS[6];
+        const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
+        const int g = lane & 15;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 16; ++it) {
+            const int S = 4 * it + (lane >> 4);
+            int V = valS[wave][S];
+            uint32_t word;
+            if ((((uint32_t)(liveMask >> (4 * it))) & 15u) == 0u) word = (uint32_t)V * 0x01010101u;   // wave-uniform
+            else {
+                const uint32_t so = offS[wave][S];
+                const bool deadRow = so == VR_IDX_DEAD;
+                const uint32_t c = ((const uint8_t *)cntS[wave])[S * 16 + g];
+                uint32_t inc = c;                                   // prefix sum within the row of 16 lanes
+                inc += dpp_u32<0x111, 0xf>(0, inc);
+                inc += dpp_u32<0x112, 0xf>(0, inc);
+                inc += dpp_u32<0x114, 0xf>(0, inc);
+                inc += dpp_u32<0x118, 0xf>(0, inc);
+                const uint32_t tokpos = (deadRow ? 0u : so) + inc - c;
+                const uint32_t *Wp = W + (tokpos >> 4);
+                const uint32_t bit0 = (tokpos & 15u) * 2u;
+                const uint32_t w0 = Wp[0], w1 = Wp[1], w2 = Wp[2], w3 = Wp[3];
+                str[lane] = w0; str[64 + lane] = w1; str[128 + lane] = w2; str[192 + lane] = w3;
+                const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, bit0);        // my first 16 tokens
+                uint32_t P = deadRow ? 1u : 0u;     // an ancestor is pruned: V is final for my voxels
+                uint32_t cb = 0;                    // bits of my tokens consumed
+                const auto node = [&](bool owner, uint32_t x, int dist) {   // one tree token (R.cpp:783-787)
+                    const bool own = owner && P == 0u;
+                    const uint32_t tok = own ? (x & 3u) : 0u;
+                    V = clamp_add(V, (int)tok, dist);
+                    P |= tok == 3u ? 1u : 0u;
+                    cb += own ? 2u : 0u;
+                };
+                uint32_t vp;
+                node(g == 0, x0, 0);                                          // depth Ds keeps the index value
+                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((uint32_t)V | (P << 8)), 0x0010);   // from lane g & ~15
+                V = (int)(vp & 255u); P = vp >> 8;
+                node((g & 7) == 0, x0 >> cb, d1);
+                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((uint32_t)V | (P << 8)), 0x0018);   // from lane g & ~7
+                V = (int)(vp & 255u); P = vp >> 8;
+                node((g & 3) == 0, x0 >> cb, d2);
+                vp = dpp_u32<0x00, 0xf>(0, (uint32_t)V | (P << 8));                                  // quad_perm [0,0,0,0]
+                V = (int)(vp & 255u); P = vp >> 8;
+                node((g & 1) == 0, x0 >> cb, d3);
+                vp = dpp_u32<0xA0, 0xf>(0, (uint32_t)V | (P << 8));                                  // quad_perm [0,0,2,2]
+                V = (int)(vp & 255u); P = vp >> 8;
+                node(true, x0 >> cb, d4);                                     // my own 4-leaf subtree's root
+                const int V4 = V;
+                const uint32_t P4 = P;
+                const auto window = [&](uint32_t bp) {      // 16 tokens from bit bp of my words
+                    const uint32_t k = bp >> 5;
+                    return __builtin_amdgcn_alignbit(str[(k + 1) * 64 + lane], str[k * 64 + lane], bp & 31u);
+                };
+                // first pair: everything up to the end of the first leaf's branch is within x0
+                node(true, x0 >> cb, d5);
+                LeafOut l0 = fine_leaf(x0 >> cb, P == 0u, V, d6, lutC1, lutC2);
+                cb += l0.bits;
+                LeafOut l1 = fine_leaf(window(bit0 + cb), P == 0u, V, d6, lutC1, lutC2);
+                cb += l1.bits;
+                // second pair
+                V = V4; P = P4;
+                const uint32_t yb = window(bit0 + cb);
+                {
+                    const uint32_t before = cb;
+                    node(true, yb, d5);
+                    LeafOut l2 = fine_leaf(yb >> (cb - before), P == 0u, V, d6, lutC1, lutC2);
+                    cb += l2.bits;
+                    LeafOut l3 = fine_leaf(window(bit0 + cb), P == 0u, V, d6, lutC1, lutC2);
+                    word = (uint32_t)l0.v | ((uint32_t)l1.v << 8) | ((uint32_t)l2.v << 16) | ((uint32_t)l3.v << 24);
+                }
+            }
+            tile[g * FD_TS + S] = word;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    tile_gather(a, tile, FD_TS, liveMask == 0ull ? 0 : 1, brick, tx, ty, tz, lane);
 }
 
 static bool tile_geometry(const BrickSet *bs, TileArgs &a)
@@ -439,8 +608,13 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
         t.ctrls = bs->mid.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
         t.cut = cut; t.idxValCut = cutVals; t.spread = bs->spread;
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
-        hipLaunchKernelGGL(k_decode_tile, dim3((unsigned)((ntiles + DEC_WAVES - 1) / DEC_WAVES), bs->B),
-                           dim3(64 * DEC_WAVES), 0, st, t);
+        t.fine = bs->fineIdx;
+        if (bs->fineValid && !getenv("VRHIP_DECODE_WALK"))
+            hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((ntiles + FD_WAVES - 1) / FD_WAVES), bs->B),
+                               dim3(64 * FD_WAVES), 0, st, t);
+        else
+            hipLaunchKernelGGL(k_decode_tile, dim3((unsigned)((ntiles + DEC_WAVES - 1) / DEC_WAVES), bs->B),
+                               dim3(64 * DEC_WAVES), 0, st, t);
     } else {
         DecodeArgs a;
         a.tree = bs->mid.tree; a.treeCap = bs->treeCap;

@@ -1350,6 +1350,7 @@ struct PruneEmitArgs {
     const uint32_t *chainLut;
     uint32_t *idxOff;              // block-local token offset of every depth-Ds node (k_concat12 makes it global)
     int64_t nIdx;
+    uint32_t *fineIdx;             // 16 bytes per depth-Ds node: tokens owned by each of its 4-leaf subtrees (k_decode_fine)
 };
 
 // The three 4 KiB pieces of a block's staging area, resolved once per thread: indexing ReconBufs (a kernel
@@ -1611,6 +1612,19 @@ k_prune_emit12(PruneEmitArgs a)
     }
     if ((t & 3) == 0)       // decode side-car index: the depth-Ds node of every 64 leaves, block-local for now
         a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + (t >> 2)] = aliveAtDs ? pos + (uint32_t)preDs : VR_IDX_DEAD;
+    {
+        // ... and, below it, how many tokens each 4-leaf subtree owns in preorder: its own nodes plus the
+        // ancestors (depth >= Ds) whose first leaf is its first leaf.  One byte each (at most 4 + 39 tokens); the
+        // decoder turns them into token offsets with a 16-lane prefix sum, so one lane decodes four voxels.
+        const int nsIn = jmin <= 6 ? (aliveAtDs ? ns - preDs : 0) : ns;
+        const bool l4 = alive && a4 != 3u;
+        const bool l30 = l4 && (a3 & 3u) != 3u, l31 = l4 && ((a3 >> 2) & 3u) != 3u;
+        const uint32_t f0 = (uint32_t)(nsIn + (alive ? 1 + (l4 ? 1 + (l30 ? cnt2[0] : 0) : 0) : 0));
+        const uint32_t f1 = (uint32_t)(l30 ? cnt2[1] : 0);
+        const uint32_t f2 = (uint32_t)(l4 ? 1 + (l31 ? cnt2[2] : 0) : 0);
+        const uint32_t f3 = (uint32_t)(l31 ? cnt2[3] : 0);
+        a.fineIdx[((int64_t)brick * a.nIdx + (base >> 6)) * 4 + t] = f0 | (f1 << 8) | (f2 << 16) | (f3 << 24);
+    }
     __syncthreads();
     const uint32_t nw = (tot + 15u) >> 4;
     const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
@@ -2293,6 +2307,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     int pruneFrom = D - 1;
+    bs->fineValid = false;
     const bool fused = !mr && D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
     if (fused) {
         PruneEmitArgs pa;
@@ -2301,8 +2316,11 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->leafStride;
         pa.rb = rb; pa.subTok = bs->blockOff; pa.nEmitBlk = bs->nEmitBlk; pa.blockL1 = bs->blockL1;
         pa.chainLut = bs->chainLut; pa.idxOff = bs->idxOff; pa.nIdx = bs->nIdx;
+        if (!bs->fineIdx && hipMalloc(&bs->fineIdx, (size_t)B * bs->nIdx * 16) != hipSuccess) return -3;
+        pa.fineIdx = (uint32_t *)bs->fineIdx;
         hipLaunchKernelGGL(k_prune_emit12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
         pruneFrom = D - 13;
+        bs->fineValid = true;
     } else if (D >= 12) {
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
