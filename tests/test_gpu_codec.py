@@ -421,3 +421,45 @@ def test_reopened_file_decodes_through_the_tile_kernel(vr, oracle, tmp_path):
     assert np.array_equal(got, want) and np.array_equal(got.reshape(shape), ref.levelCut())
     cut = u.levelCut(9).cpu().numpy()          # progressive cut above the index level, foreign stream
     assert np.array_equal(cut.reshape(shape), ref.levelCutProgressive(9))
+
+
+def _mixed_volume(rng, shape):
+    """Constant boxes, noisy patches and saturated ends: pruned nodes of every size next to long grown branches."""
+    v = np.full(shape, int(rng.integers(0, 256)), np.int64)
+    for _ in range(int(rng.integers(2, 7))):
+        a = [sorted(rng.integers(0, s + 1, 2)) for s in shape]
+        v[a[0][0]:a[0][1], a[1][0]:a[1][1], a[2][0]:a[2][1]] = rng.integers(0, 256)
+    for _ in range(int(rng.integers(1, 4))):
+        a = [sorted(rng.integers(0, s + 1, 2)) for s in shape]
+        sub = v[a[0][0]:a[0][1], a[1][0]:a[1][1], a[2][0]:a[2][1]]
+        sub += rng.integers(-int(rng.integers(1, 60)), 60, sub.shape)
+    if rng.random() < 0.5:
+        m = rng.random(shape) < 0.05
+        v[m] = rng.integers(0, 256, int(m.sum()))
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 128), (8, 16, 128), (16, 16, 256), (8, 8, 512)])
+def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shape):
+    """k_decode_fine (one lane per four voxels, token offsets from the fused encoder's per-4-leaf counts) against
+    k_decode_tile (one lane walks 64 voxels; VRHIP_DECODE_WALK=1) and against the oracle's levelCut, full depth
+    and progressive cuts on both sides of the index level."""
+    rng = np.random.default_rng(1000 + shape[0] * shape[2])
+    z, y, x = shape
+    for case in range(6):
+        tol = int(rng.choice([1, 2, 6, 9])); ep = int(rng.choice([1, 2, 5]))
+        vol = _mixed_volume(rng, shape) if case else rng.integers(0, 256, shape, dtype=np.uint8)
+        ref = oracle.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep).build()
+        bs = vr.BrickSet(1, (x, y, z), tol, ep)
+        bs.build(vol.copy())
+        assert np.array_equal(bs.tree(0), ref.tree)
+        D = ref.origTreeDepth
+        cuts = [None, D, D - 1, D - 5, D - 6, D - 7, 3, int(rng.integers(1, ref.maxTreeDepth + 1))]
+        for cut in cuts:
+            want = ref.levelCut() if cut is None else ref.levelCutProgressive(cut)
+            fine = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
+            monkeypatch.setenv("VRHIP_DECODE_WALK", "1")
+            walk = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
+            monkeypatch.delenv("VRHIP_DECODE_WALK")
+            assert np.array_equal(fine, want), (case, tol, ep, cut)
+            assert np.array_equal(walk, want), (case, tol, ep, cut)

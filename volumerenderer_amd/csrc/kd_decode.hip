@@ -453,29 +453,35 @@ k_decode_fine(TileArgs a)
     uint32_t *tile = tileS[wave];
     uint32_t *str = strS[wave];
     const bool tileValid = tileId < a.tilesX * a.tilesY * a.tilesZ;
-    if (threadIdx.x < 16) {
-        const uint8_t *dmap = a.ctrls[brick].distanceMap;
-        const int t = threadIdx.x;
-        const int depth = t < 8 ? a.Ds + (t < 7 ? t : 0) : a.D + (t - 8);
-        dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];      // as in k_decode_tile
-    }
-    __syncthreads();
-    chain_tables(dmS, lutC1, lutC2);
-    __syncthreads();
-    if (!tileValid) return;
     const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
-    const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
-    const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
-    const uint32_t off = a.idxOff[(int64_t)brick * a.nIdx + s];
-    const int val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
+    uint32_t off = VR_IDX_DEAD;
+    int val0 = 0;
+    if (tileValid) {
+        const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
+        const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
+        off = a.idxOff[(int64_t)brick * a.nIdx + s];
+        val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
+        if (off != VR_IDX_DEAD) *(uint4 *)&cntS[wave][lane * 4] = *(const uint4 *)(a.fine + ((int64_t)brick * a.nIdx + s) * 16);
+    }
     const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
+    // blocks whose tiles all lie in pruned regions (constant bricks, pure fluid) need no tables
+    if (__syncthreads_or(liveMask != 0ull ? 1 : 0)) {
+        if (threadIdx.x < 16) {
+            const uint8_t *dmap = a.ctrls[brick].distanceMap;
+            const int t = threadIdx.x;
+            const int depth = t < 8 ? a.Ds + (t < 7 ? t : 0) : a.D + (t - 8);
+            dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];      // as in k_decode_tile
+        }
+        __syncthreads();
+        chain_tables(dmS, lutC1, lutC2);
+        __syncthreads();
+    }
+    if (!tileValid) return;
     if (liveMask == 0ull) tile[lane] = (uint32_t)val0 * 0x01010101u;      // as in k_decode_tile
     else {
-        uint4 cv = make_uint4(0, 0, 0, 0);
-        if (off != VR_IDX_DEAD) cv = *(const uint4 *)(a.fine + ((int64_t)brick * a.nIdx + s) * 16);
         offS[wave][lane] = off;
         valS[wave][lane] = (uint8_t)val0;
-        *(uint4 *)&cntS[wave][lane * 4] = cv;
+        if (off == VR_IDX_DEAD) *(uint4 *)&cntS[wave][lane * 4] = make_uint4(0, 0, 0, 0);
         const int d1 = dmS[1], d2 = dmS[2], d3 = dmS[3], d4 = dmS[4], d5 = dmS[5], d6 = dmS[6];
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
         const int g = lane & 15;
