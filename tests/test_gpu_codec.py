@@ -463,3 +463,9 @@ def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shap
             monkeypatch.delenv("VRHIP_DECODE_WALK")
             assert np.array_equal(fine, want), (case, tol, ep, cut)
             assert np.array_equal(walk, want), (case, tol, ep, cut)
+        # the same bytes installed as a foreign stream (what open() does): the per-4-leaf counts then come from
+        # the host-side parse of the bytes, not from the encoder
+        fs = vr.BrickSet(1, (x, y, z), tol, ep)
+        fs.set_tree(0, ref.tree, ref.numActiveNodes, ref.distanceMap)
+        assert np.array_equal(fs.decode().cpu().numpy().reshape(shape), ref.levelCut()), (case, tol, ep, "foreign")
+        assert np.array_equal(fs.decode(cut_depth=D - 2).cpu().numpy().reshape(shape), ref.levelCutProgressive(D - 2))

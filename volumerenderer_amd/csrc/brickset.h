@@ -43,7 +43,7 @@ struct BrickSet {
     uint8_t *idxVal = nullptr;  // B * nIdx  decoded scalar of that root (or of the pruned ancestor)
     uint8_t *idxValCut = nullptr; // B * nIdx  progressive cut above the index level: ancestor scalars
     uint8_t *fineIdx = nullptr;   // B * nIdx * 16  tokens owned by each 4-leaf subtree of a depth-Ds node (fused encoder only)
-    bool fineValid = false;       // fineIdx describes the current stream
+    std::vector<uint8_t> fineHas; // per brick: fineIdx describes its current stream (all set -> k_decode_fine)
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
     bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream
@@ -66,7 +66,8 @@ int decode_launch(BrickSet *bs, uint8_t *outDev, int cutDepth, hipStream_t st);
 int cut_values_from_stream(BrickSet *bs, const uint8_t *treeHost, int64_t numActive, const uint8_t *dmapHost, int cut,
                            std::vector<uint8_t> &vals);
 int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *treeHost, int64_t numActive,
-                            const uint8_t *dmapHost, std::vector<uint32_t> &offs, std::vector<uint8_t> &vals);
+                            const uint8_t *dmapHost, std::vector<uint32_t> &offs, std::vector<uint8_t> &vals,
+                            std::vector<uint8_t> &fine);
 void make_geom(Geom &g, const int64_t dims[3]);
 void make_lut(const Geom &g, int K, std::vector<uint32_t> &lut);
 

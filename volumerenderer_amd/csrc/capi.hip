@@ -410,9 +410,10 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     const int64_t need = (num_active + 3) / 4;
     if (tree_bytes < need || need > b.treeCap) return VR_ERR_FORMAT;
     std::vector<uint32_t> offs;
-    std::vector<uint8_t> vals;
-    if (build_index_from_stream(&b, brick, tree, num_active, dmap, offs, vals) != 0) return VR_ERR_FORMAT;
+    std::vector<uint8_t> vals, fine;
+    if (build_index_from_stream(&b, brick, tree, num_active, dmap, offs, vals, fine) != 0) return VR_ERR_FORMAT;
     if (!b.built) { // first foreign tree: other bricks stay empty until set
+        b.fineHas.assign((size_t)b.B, 1);   // (their index is all "pruned": no counts are read)
         HIPCHK(hipMemset(b.mid.ctrl, 0, (size_t)b.B * sizeof(Ctrl)));
         std::vector<uint32_t> dead((size_t)b.B * b.nIdx, VR_IDX_DEAD);
         HIPCHK(hipMemcpy(b.idxOff, dead.data(), dead.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -434,7 +435,13 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     b.built = true;
     b.hostCtrlValid = true;
     b.foreign = true;
-    b.fineValid = false;
+    if ((int)b.fineHas.size() != b.B) b.fineHas.assign((size_t)b.B, 0);
+    b.fineHas[(size_t)brick] = 0;
+    if (!fine.empty()) {
+        if (!b.fineIdx) HIPCHK(hipMalloc(&b.fineIdx, (size_t)b.B * b.nIdx * 16));
+        HIPCHK(hipMemcpy(b.fineIdx + (size_t)brick * b.nIdx * 16, fine.data(), fine.size(), hipMemcpyHostToDevice));
+        b.fineHas[(size_t)brick] = 1;
+    }
     if ((int)b.hostTree.size() != b.B) b.hostTree.assign((size_t)b.B, std::vector<uint8_t>());
     b.hostTree[brick].assign(tree, tree + need);
     return VR_OK;

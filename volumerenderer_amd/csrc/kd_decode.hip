@@ -169,6 +169,13 @@ __device__ __forceinline__ int med3i(int x, int lo, int hi)
     return r;
 }
 
+__device__ __forceinline__ int mad24i(int x, int y, int z)
+{   // x * y + z for operands within 24 bits, one full-rate instruction
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
 __device__ __forceinline__ int clamp_add(int pv, int tok, int dist)
 {   // decoder step R.cpp:783-787 / 814-818, branch-free
     const int delta = tok == 1 ? dist : (tok == 2 ? -dist : 0);
@@ -182,7 +189,7 @@ __device__ __forceinline__ int clamp_add(int pv, int tok, int dist)
 __device__ __forceinline__ void chain_tables(const uint8_t *dmS, uint32_t *lutC1, uint32_t *lutC2)
 {
     const int idx = threadIdx.x;
-    for (int tb = 0; tb < 2; ++tb) {
+    for (int tb = lutC1 ? 0 : 1; tb < 2; ++tb) {
         const int first = tb == 0 ? 1 : 5, n = tb == 0 ? 4 : 3;
         if (tb == 1 && idx >= 64) break;
         int A = 0, LO = 0, HI = 255, len = 0, term = 0;
@@ -417,24 +424,25 @@ k_decode_tile(TileArgs a)
 #define FD_WAVES 4
 #define FD_TS 68          // tile row stride in words: lanes (g, S) -> bank 4g + S, conflict-free
 
-struct LeafOut { int v; uint32_t bits; };
-
-// one voxel leaf: its code at the low end of `y`, then its grown branch (R.cpp:655-704 as the decoder sees it)
-__device__ __forceinline__ LeafOut fine_leaf(uint32_t y, bool own, int vp, int d6, const uint32_t *lutC1, const uint32_t *lutC2)
+// voxel-leaf table (256 threads, 1024 entries): a leaf's code and the first four tokens of its grown branch,
+// composed like chain_tables: v -> min(max(v + A, LO), HI).  [0:10) A + 512, [10:18) LO, [18:26) HI, [26:29) tokens
+// consumed (code included), 29 ended (pruned leaf or terminator; otherwise branch tokens 5-7 follow: lutC2).
+__device__ __forceinline__ void leaf_table(const uint8_t *dmS, uint32_t *lutL)
 {
-    const uint32_t tok = own ? (y & 3u) : 0u;
-    const int vl = clamp_add(vp, (int)tok, d6);
-    const bool lf = own && tok != 3u;
-    const uint32_t xc = y >> 2;
-    const uint32_t e1 = lutC1[xc & 255u], e2 = lutC2[(xc >> 8) & 63u];
-    const int b1 = med3i(vl + (int)(e1 & 1023u) - 256, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
-    const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
-    const bool more = ((e1 >> 29) & 1u) == 0u;
-    const uint32_t clen = ((e1 >> 26) & 7u) + (more ? ((e2 >> 26) & 7u) : 0u);
-    LeafOut o;
-    o.v = lf ? (more ? b2 : b1) : vl;
-    o.bits = own ? 2u + (lf ? 2u * clen : 0u) : 0u;
-    return o;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        int A = 0, LO = 0, HI = 255, len = 0, term = 0;
+        for (int q = 0; q < 5; ++q) {
+            const int tok = (idx >> (2 * q)) & 3;
+            ++len;
+            if (tok == 3) { term = 1; break; }
+            const int dist = q == 0 ? dmS[6] : dmS[8 + q];
+            const int dl = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+            A += dl;
+            LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
+            HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
+        }
+        lutL[idx] = (uint32_t)(A + 512) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) | ((uint32_t)term << 29);
+    }
 }
 
 __global__ void __launch_bounds__(64 * FD_WAVES)
@@ -446,7 +454,7 @@ k_decode_fine(TileArgs a)
     __shared__ uint32_t cntS[FD_WAVES][64 * 4];         // ... the 16 owned-token counts (bytes)
     __shared__ uint8_t valS[FD_WAVES][64];              // ... the scalar its root starts from
     __shared__ uint8_t dmS[16];
-    __shared__ uint32_t lutC1[256], lutC2[64];
+    __shared__ uint32_t lutL[1024], lutC2[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * FD_WAVES + wave;
@@ -473,7 +481,8 @@ k_decode_fine(TileArgs a)
             dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];      // as in k_decode_tile
         }
         __syncthreads();
-        chain_tables(dmS, lutC1, lutC2);
+        chain_tables(dmS, nullptr, lutC2);
+        leaf_table(dmS, lutL);
         __syncthreads();
     }
     if (!tileValid) return;
@@ -482,76 +491,99 @@ k_decode_fine(TileArgs a)
         offS[wave][lane] = off;
         valS[wave][lane] = (uint8_t)val0;
         if (off == VR_IDX_DEAD) *(uint4 *)&cntS[wave][lane * 4] = make_uint4(0, 0, 0, 0);
-        const int d1 = dmS[1], d2 = dmS[2], d3 = dmS[3], d4 = dmS[4], d5 = dmS[5], d6 = dmS[6];
+        const int d1 = dmS[1], d2 = dmS[2], d3 = dmS[3], d4 = dmS[4], d5 = dmS[5];
         const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
         const int g = lane & 15;
+        // which ancestors (depth Ds .. Ds+3) this lane owns, as all-ones / zero masks
+        const uint32_t o0 = g == 0 ? ~0u : 0u, o1 = (g & 7) == 0 ? ~0u : 0u, o2 = (g & 3) == 0 ? ~0u : 0u, o3 = (g & 1) == 0 ? ~0u : 0u;
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        // the stream words of step `it` are requested one step ahead
+        uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nbit0 = 0, nM = 0;
+        const auto request = [&](int it) {
+            if ((((uint32_t)(liveMask >> (4 * it))) & 15u) == 0u) return;       // wave-uniform
+            const int S = 4 * it + (lane >> 4);
+            const uint32_t so = offS[wave][S];
+            const uint32_t c = ((const uint8_t *)cntS[wave])[S * 16 + g];
+            uint32_t inc = c;                                   // prefix sum within the row of 16 lanes
+            inc += dpp_u32<0x111, 0xf>(0, inc);
+            inc += dpp_u32<0x112, 0xf>(0, inc);
+            inc += dpp_u32<0x114, 0xf>(0, inc);
+            inc += dpp_u32<0x118, 0xf>(0, inc);
+            const bool deadRow = so == VR_IDX_DEAD;
+            const uint32_t tokpos = (deadRow ? 0u : so) + inc - c;
+            const uint32_t *Wp = W + (tokpos >> 4);
+            nbit0 = (tokpos & 15u) * 2u;
+            nM = deadRow ? 0u : ~0u;
+            nw0 = Wp[0]; nw1 = Wp[1]; nw2 = Wp[2]; nw3 = Wp[3];
+        };
+        request(0);
         for (int it = 0; it < 16; ++it) {
             const int S = 4 * it + (lane >> 4);
             int V = valS[wave][S];
             uint32_t word;
-            if ((((uint32_t)(liveMask >> (4 * it))) & 15u) == 0u) word = (uint32_t)V * 0x01010101u;   // wave-uniform
+            const bool liveStep = (((uint32_t)(liveMask >> (4 * it))) & 15u) != 0u;   // wave-uniform
+            const uint32_t w0 = nw0, w1 = nw1, w2 = nw2, w3 = nw3, bit0 = nbit0;
+            uint32_t M = nM;                    // all ones while no ancestor is pruned (else V is final for my voxels)
+            if (it + 1 < 16) request(it + 1);
+            if (!liveStep) word = (uint32_t)V * 0x01010101u;
             else {
-                const uint32_t so = offS[wave][S];
-                const bool deadRow = so == VR_IDX_DEAD;
-                const uint32_t c = ((const uint8_t *)cntS[wave])[S * 16 + g];
-                uint32_t inc = c;                                   // prefix sum within the row of 16 lanes
-                inc += dpp_u32<0x111, 0xf>(0, inc);
-                inc += dpp_u32<0x112, 0xf>(0, inc);
-                inc += dpp_u32<0x114, 0xf>(0, inc);
-                inc += dpp_u32<0x118, 0xf>(0, inc);
-                const uint32_t tokpos = (deadRow ? 0u : so) + inc - c;
-                const uint32_t *Wp = W + (tokpos >> 4);
-                const uint32_t bit0 = (tokpos & 15u) * 2u;
-                const uint32_t w0 = Wp[0], w1 = Wp[1], w2 = Wp[2], w3 = Wp[3];
                 str[lane] = w0; str[64 + lane] = w1; str[128 + lane] = w2; str[192 + lane] = w3;
                 const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, bit0);        // my first 16 tokens
-                uint32_t P = deadRow ? 1u : 0u;     // an ancestor is pruned: V is final for my voxels
                 uint32_t cb = 0;                    // bits of my tokens consumed
-                const auto node = [&](bool owner, uint32_t x, int dist) {   // one tree token (R.cpp:783-787)
-                    const bool own = owner && P == 0u;
-                    const uint32_t tok = own ? (x & 3u) : 0u;
-                    V = clamp_add(V, (int)tok, dist);
-                    P |= tok == 3u ? 1u : 0u;
-                    cb += own ? 2u : 0u;
+                // one tree token (R.cpp:783-787) where mask m is set: as a signed 2-bit field, code 1 -> +1, code 2 -> -2,
+                // code 3 -> -1, so (s + 1) >> 1 is the sign of the step and s == -1 the pruned node
+                const auto node = [&](uint32_t x, uint32_t m, int dist) {
+                    const int s2 = __builtin_amdgcn_sbfe((int)x, cb, 2) & (int)m;
+                    V = med3i(mad24i((s2 + 1) >> 1, dist, V), 0, 255);
+                    M = s2 == -1 ? 0u : M;
+                    cb += m & 2u;
                 };
                 uint32_t vp;
-                node(g == 0, x0, 0);                                          // depth Ds keeps the index value
-                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((uint32_t)V | (P << 8)), 0x0010);   // from lane g & ~15
-                V = (int)(vp & 255u); P = vp >> 8;
-                node((g & 7) == 0, x0 >> cb, d1);
-                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((uint32_t)V | (P << 8)), 0x0018);   // from lane g & ~7
-                V = (int)(vp & 255u); P = vp >> 8;
-                node((g & 3) == 0, x0 >> cb, d2);
-                vp = dpp_u32<0x00, 0xf>(0, (uint32_t)V | (P << 8));                                  // quad_perm [0,0,0,0]
-                V = (int)(vp & 255u); P = vp >> 8;
-                node((g & 1) == 0, x0 >> cb, d3);
-                vp = dpp_u32<0xA0, 0xf>(0, (uint32_t)V | (P << 8));                                  // quad_perm [0,0,2,2]
-                V = (int)(vp & 255u); P = vp >> 8;
-                node(true, x0 >> cb, d4);                                     // my own 4-leaf subtree's root
+                node(x0, M & o0, 0);                                          // depth Ds keeps the index value
+                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((M & 0xFFFFFF00u) | (uint32_t)V), 0x0010);   // from lane g & ~15
+                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
+                node(x0, M & o1, d1);
+                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((M & 0xFFFFFF00u) | (uint32_t)V), 0x0018);   // from lane g & ~7
+                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
+                node(x0, M & o2, d2);
+                vp = dpp_u32<0x00, 0xf>(0, (M & 0xFFFFFF00u) | (uint32_t)V);                                   // quad_perm [0,0,0,0]
+                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
+                node(x0, M & o3, d3);
+                vp = dpp_u32<0xA0, 0xf>(0, (M & 0xFFFFFF00u) | (uint32_t)V);                                   // quad_perm [0,0,2,2]
+                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
+                node(x0, M, d4);                                              // my own 4-leaf subtree's root
                 const int V4 = V;
-                const uint32_t P4 = P;
+                const uint32_t M4 = M;
                 const auto window = [&](uint32_t bp) {      // 16 tokens from bit bp of my words
                     const uint32_t k = bp >> 5;
                     return __builtin_amdgcn_alignbit(str[(k + 1) * 64 + lane], str[k * 64 + lane], bp & 31u);
                 };
+                // one voxel leaf: its code + grown branch at the low end of y (R.cpp:655-704 as the decoder sees it)
+                const auto leaf = [&](uint32_t y) {
+                    const uint32_t e1 = lutL[y & 1023u], e2 = lutC2[(y >> 10) & 63u];
+                    const int b1 = med3i(V + (int)(e1 & 1023u) - 512, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
+                    const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
+                    const bool ended = ((e1 >> 29) & 1u) != 0u;
+                    const uint32_t len = ((e1 >> 26) & 7u) + (ended ? 0u : ((e2 >> 26) & 7u));
+                    cb += (2u * len) & M;
+                    const int v = ended ? b1 : b2;
+                    return (uint32_t)(M ? v : V);
+                };
                 // first pair: everything up to the end of the first leaf's branch is within x0
-                node(true, x0 >> cb, d5);
-                LeafOut l0 = fine_leaf(x0 >> cb, P == 0u, V, d6, lutC1, lutC2);
-                cb += l0.bits;
-                LeafOut l1 = fine_leaf(window(bit0 + cb), P == 0u, V, d6, lutC1, lutC2);
-                cb += l1.bits;
+                node(x0, M, d5);
+                word = leaf(x0 >> cb);
+                word |= leaf(window(bit0 + cb)) << 8;
                 // second pair
-                V = V4; P = P4;
-                const uint32_t yb = window(bit0 + cb);
+                V = V4; M = M4;
                 {
-                    const uint32_t before = cb;
-                    node(true, yb, d5);
-                    LeafOut l2 = fine_leaf(yb >> (cb - before), P == 0u, V, d6, lutC1, lutC2);
-                    cb += l2.bits;
-                    LeafOut l3 = fine_leaf(window(bit0 + cb), P == 0u, V, d6, lutC1, lutC2);
-                    word = (uint32_t)l0.v | ((uint32_t)l1.v << 8) | ((uint32_t)l2.v << 16) | ((uint32_t)l3.v << 24);
+                    const uint32_t yb = window(bit0 + cb), before = cb;
+                    cb = 0;
+                    node(yb, M, d5);
+                    const uint32_t used = cb;
+                    cb = before + used;
+                    word |= leaf(yb >> used) << 16;
+                    word |= leaf(window(bit0 + cb)) << 24;
                 }
             }
             tile[g * FD_TS + S] = word;
@@ -615,7 +647,9 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
         t.cut = cut; t.idxValCut = cutVals; t.spread = bs->spread;
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
         t.fine = bs->fineIdx;
-        if (bs->fineValid && !getenv("VRHIP_DECODE_WALK"))
+        bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !getenv("VRHIP_DECODE_WALK");
+        for (int i = 0; useFine && i < bs->B; ++i) useFine = bs->fineHas[(size_t)i] != 0;
+        if (useFine)
             hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((ntiles + FD_WAVES - 1) / FD_WAVES), bs->B),
                                dim3(64 * FD_WAVES), 0, st, t);
         else
@@ -678,11 +712,20 @@ int cut_values_from_stream(BrickSet *bs, const uint8_t *tree, int64_t numActive,
 // Serial pass over a foreign stream (host): the side-car index from the bytes alone.
 // Also validates the grammar.  Returns 0 or a negative code.
 int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *tree, int64_t numActive, const uint8_t *dmap,
-                            std::vector<uint32_t> &offs, std::vector<uint8_t> &vals)
+                            std::vector<uint32_t> &offs, std::vector<uint8_t> &vals, std::vector<uint8_t> &fine)
 {
     const int D = bs->D, Ds = bs->Ds;
     offs.assign((size_t)bs->nIdx, VR_IDX_DEAD);
     vals.assign((size_t)bs->nIdx, 0);
+    // K == 6: tokens owned by each 4-leaf subtree of a depth-Ds node, what k_prune_emit12 leaves for k_decode_fine.
+    // A token at depth >= Ds belongs to the 4-leaf subtree that holds its node's first leaf.
+    const bool wantFine = bs->K == 6 && D >= 6;
+    fine.assign(wantFine ? (size_t)bs->nIdx * 16 : 0, 0);
+    auto own = [&](uint32_t path, int j) {
+        if (!wantFine || j < Ds) return;
+        const uint32_t first = path << (D - j);     // first leaf (rank) below the node
+        fine[(size_t)(first >> 6) * 16 + ((first >> 2) & 15u)] += 1;
+    };
     auto get = [&](int64_t p) { return (tree[p >> 2] >> ((p & 3) * 2)) & 3; };
     int v[VR_MAX_DEPTH];
     int64_t pos = 0;
@@ -695,6 +738,7 @@ int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *tree, int64_
         int val = j == 0 ? dmap[0] : apply_code(v[j - 1], tok, dmap[j]);
         v[j] = val;
         if (j == Ds) { offs[path] = (uint32_t)here; vals[path] = (uint8_t)val; }
+        own(path, j);
         bool terminal = false;
         if (tok == 3) {
             if (j < Ds) {
@@ -705,6 +749,7 @@ int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *tree, int64_
         } else if (j == D) {
             for (int c = 1; c <= VR_CHAIN_LEVELS; ++c) {
                 if (pos >= numActive) return -2;
+                own(path, j);
                 if (get(pos++) == 3) break;
             }
             terminal = true;

@@ -2307,7 +2307,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     ReconBufs rb{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     int pruneFrom = D - 1;
-    bs->fineValid = false;
+    bs->fineHas.assign((size_t)B, 0);
     const bool fused = !mr && D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
     if (fused) {
         PruneEmitArgs pa;
@@ -2320,7 +2320,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.fineIdx = (uint32_t *)bs->fineIdx;
         hipLaunchKernelGGL(k_prune_emit12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
         pruneFrom = D - 13;
-        bs->fineValid = true;
+        bs->fineHas.assign((size_t)B, 1);
     } else if (D >= 12) {
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
