@@ -540,7 +540,11 @@ k_decode_fine(TileArgs a)
                     cb += m & 2u;
                 };
                 uint32_t vp;
-                node(x0, M & o0, 0);                                          // depth Ds keeps the index value
+                {   // depth Ds keeps the index value: only "pruned" and the token matter
+                    const uint32_t m = M & o0;
+                    M = (__builtin_amdgcn_sbfe((int)x0, 0, 2) & (int)m) == -1 ? 0u : M;
+                    cb = m & 2u;
+                }
                 vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((M & 0xFFFFFF00u) | (uint32_t)V), 0x0010);   // from lane g & ~15
                 V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
                 node(x0, M & o1, d1);
