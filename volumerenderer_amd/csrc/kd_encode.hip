@@ -642,7 +642,13 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
     const uint32_t d2 = (uint32_t)dist * 0x10001u, dm2 = (uint32_t)distM * 0x10001u, dp2 = (uint32_t)distP * 0x10001u;
-    uint32_t e0 = 0, em = 0, ep = 0, wa = 0, wb = 0, rw[4], rprev = 0;
+    uint32_t e0 = 0, em = 0, ep = 0, wa = 0, wb = 0, rw[4] = {tw[0], tw[1], tw[2], tw[3]}, rprev = 0;
+    // a wave whose 1024 truths all equal their parents' reconstruction (constant regions) has nothing to decide:
+    // every code is "keep", the reconstruction is the truth, the error 0 at any distance (pd = 0 in encodeNode)
+    const uint32_t differs = (tw[0] ^ __builtin_amdgcn_perm(0, pw[0], 0x01010000u)) | (tw[1] ^ __builtin_amdgcn_perm(0, pw[0], 0x03030202u)) |
+                             (tw[2] ^ __builtin_amdgcn_perm(0, pw[1], 0x01010000u)) | (tw[3] ^ __builtin_amdgcn_perm(0, pw[1], 0x03030202u));
+    const bool busy = __ballot(differs != 0u) != 0ull;
+    if (busy)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {                        // sibling pair j: nodes 2j, 2j+1, parent byte j
         const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
@@ -665,9 +671,12 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
     *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
     // per-lane sums are < 2^21, a wave's < 2^27: 32-bit DPP scans, the total in lane 63
-    const unsigned long long s0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(e0), 63),
-                             sm = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(em), 63),
-                             sp = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(ep), 63);
+    unsigned long long s0 = 0, sm = 0, sp = 0;
+    if (busy) {
+        s0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(e0), 63);
+        sm = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(em), 63);
+        sp = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(ep), 63);
+    }
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         blockErr[(int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = s0;   // 1024 nodes per wave
@@ -1421,6 +1430,16 @@ k_prune_emit12(PruneEmitArgs a)
     uint32_t bothMask = 0;
     vr_s16x2 mxB = (vr_s16x2)(0), mxA = (vr_s16x2)(0), l1p = (vr_s16x2)(0);
     const int nsteps = a.maxDepth - D;    // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
+    // a wave whose 1024 leaves all carry code 0 and are reproduced exactly (constant regions) prunes them all:
+    // one '3' per leaf, no branches, no statistics to add
+    const bool plain = tol >= 1 && cpk == 0u && tv.x == rv.x && tv.y == rv.y && tv.z == rv.z && tv.w == rv.w;
+    const bool busy = __ballot(!plain) != 0ull;
+    if (!busy) {
+        bothMask = 0xFFu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { nt[j] = 0x00010001u; Lb[j] = 0x00030003u; }
+    }
+    if (busy)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {          // two halves of four sibling pairs: halves the transient registers
         uint32_t T2[4], m[4], sg[4], act[4];
