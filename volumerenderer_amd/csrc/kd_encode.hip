@@ -1422,7 +1422,23 @@ k_prune_emit12(PruneEmitArgs a)
     lutS[t] = lutV;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
     for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
-    __syncthreads();
+    // ---- a block of 4096 exactly reproduced leaves under all-"keep" codes (constant regions) is one pruned subtree:
+    // its string is the single token 3, its index entries are "pruned", its statistics zero.  Only the root's code
+    // is written back: nothing reads the codes below a pruned node for anything but their (equal) scalars.
+    const bool plain = tol >= 1 && cpk == 0u && tv.x == rv.x && tv.y == rv.y && tv.z == rv.z && tv.w == rv.w;
+    const uint32_t myCodes = ((c4B >> ((int)(n4 & 3) * 2)) & 3u) | ((c3B >> ((int)(n3 & 3) * 2)) & 15u) | c2B | c1H |
+                             ((upB >> ((int)(niU & 3) * 2)) & 3u);
+    if (__syncthreads_and(plain && myCodes == 0u)) {
+        if (t == 0) {
+            cset3(Cb, ((int64_t)1 << (D - 12)) + blk);
+            a.subTok[(int64_t)brick * a.nEmitBlk + blk] = 1;
+            const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
+            *pe_stage(stg, 0) = 3u;
+        }
+        if (t < 4) a.blockL1[(int64_t)brick * a.nEmitBlk + (size_t)blk * 4 + t] = stat_pack(0, 0, 0);
+        if (t < 64) a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + t] = VR_IDX_DEAD;
+        return;
+    }
     // ---- leaves: prune (R.cpp:618-626), grown branches (R.cpp:655-704); sibling leaves share packed 16-bit lanes
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
     const uint32_t tol2 = (uint32_t)tol * 0x10001u;
@@ -1432,7 +1448,6 @@ k_prune_emit12(PruneEmitArgs a)
     const int nsteps = a.maxDepth - D;    // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
     // a wave whose 1024 leaves all carry code 0 and are reproduced exactly (constant regions) prunes them all:
     // one '3' per leaf, no branches, no statistics to add
-    const bool plain = tol >= 1 && cpk == 0u && tv.x == rv.x && tv.y == rv.y && tv.z == rv.z && tv.w == rv.w;
     const bool busy = __ballot(!plain) != 0ull;
     if (!busy) {
         bothMask = 0xFFu;
