@@ -452,7 +452,6 @@ k_decode_fine(TileArgs a)
     __shared__ uint32_t strS[FD_WAVES][5 * 64];         // [word][lane]: my 4 stream words (+ 1 never needed but read)
     __shared__ uint32_t offS[FD_WAVES][64];             // per subtree of the tile: token offset of its root
     __shared__ uint32_t cntS[FD_WAVES][64 * 4];         // ... the 16 owned-token counts (bytes)
-    __shared__ uint8_t valS[FD_WAVES][64];              // ... the scalar its root starts from
     __shared__ uint8_t dmS[16];
     __shared__ uint32_t lutL[1024], lutC2[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -464,12 +463,13 @@ k_decode_fine(TileArgs a)
     const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
     uint32_t off = VR_IDX_DEAD;
     int val0 = 0;
+    uint4 cv = make_uint4(0, 0, 0, 0);
     if (tileValid) {
         const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
         const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
         off = a.idxOff[(int64_t)brick * a.nIdx + s];
         val0 = a.cut < a.Ds ? a.idxValCut[(int64_t)brick * a.nIdx + s] : a.idxVal[(int64_t)brick * a.nIdx + s];
-        if (off != VR_IDX_DEAD) *(uint4 *)&cntS[wave][lane * 4] = *(const uint4 *)(a.fine + ((int64_t)brick * a.nIdx + s) * 16);
+        if (off != VR_IDX_DEAD) cv = *(const uint4 *)(a.fine + ((int64_t)brick * a.nIdx + s) * 16);
     }
     const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
     // blocks whose tiles all lie in pruned regions (constant bricks, pure fluid) need no tables
@@ -489,13 +489,59 @@ k_decode_fine(TileArgs a)
     if (liveMask == 0ull) tile[lane] = (uint32_t)val0 * 0x01010101u;      // as in k_decode_tile
     else {
         offS[wave][lane] = off;
-        valS[wave][lane] = (uint8_t)val0;
-        if (off == VR_IDX_DEAD) *(uint4 *)&cntS[wave][lane * 4] = make_uint4(0, 0, 0, 0);
+        *(uint4 *)&cntS[wave][lane * 4] = cv;
         const int d1 = dmS[1], d2 = dmS[2], d3 = dmS[3], d4 = dmS[4], d5 = dmS[5];
-        const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
+        const uint8_t *TB = a.tree + (int64_t)brick * a.treeCap;
+        const uint32_t *W = (const uint32_t *)TB;
+        {
+            // ---- once per tile, one lane per block: the 15 nodes of depths Ds .. Ds+3.  Their tokens head the runs of
+            // the even 4-leaf subtrees (prefix sums of the counts); every subtree's tile word starts out as the scalar
+            // its root hangs from (the final word where an ancestor is pruned), replicated.
+            const bool deadB = off == VR_IDX_DEAD;
+            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+            uint32_t P[8], x[8];
+            P[0] = deadB ? 0u : off;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t pr = (cw[i] & 0x00FF00FFu) + ((cw[i] >> 8) & 0x00FF00FFu);     // two pair sums
+                P[2 * i + 1] = P[2 * i] + (pr & 0xFFFFu);
+                if (i < 3) P[2 * i + 2] = P[2 * i + 1] + (pr >> 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {           // >= 13 tokens from token P[i] on (one unaligned load)
+                struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+                x[i] = ((const U32u *)(TB + (P[i] >> 2)))->v >> ((P[i] & 3u) * 2u);
+            }
+            const auto step = [](int &v, bool &al, uint32_t tok, int dist) {    // R.cpp:783-787 under "not pruned yet"
+                tok = al ? (tok & 3u) : 0u;
+                v = clamp_add(v, (int)tok, dist);
+                al = al && tok != 3u;
+            };
+            int v0 = val0;
+            bool a0 = !deadB;
+            step(v0, a0, x[0], 0);                                   // depth Ds keeps the index value
+            int v1[2], v2[4], v3[8];
+            bool a1[2], a2[4], a3[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {           // owners: subtrees 0 (after 1 token), 8
+                v1[i] = v0; a1[i] = a0;
+                step(v1[i], a1[i], i == 0 ? x[0] >> 2 : x[4], d1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {           // owners: subtrees 0 (after 2), 4, 8 (after 1), 12
+                v2[i] = v1[i >> 1]; a2[i] = a1[i >> 1];
+                step(v2[i], a2[i], x[2 * i] >> (i == 0 ? 4 : (i == 2 ? 2 : 0)), d2);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {           // owners: subtrees 0 (after 3), 2, 4 (after 1), 6, 8 (after 2), 10, 12 (after 1), 14
+                v3[i] = v2[i >> 1]; a3[i] = a2[i >> 1];
+                step(v3[i], a3[i], x[i] >> (i == 0 ? 6 : (i == 4 ? 4 : ((i & 1) ? 0 : 2))), d3);
+            }
+#pragma unroll
+            for (int gg = 0; gg < 16; ++gg) tile[gg * FD_TS + lane] = (uint32_t)v3[gg >> 1] * 0x01010101u;
+        }
         const int g = lane & 15;
-        // which ancestors (depth Ds .. Ds+3) this lane owns, as all-ones / zero masks
-        const uint32_t o0 = g == 0 ? ~0u : 0u, o1 = (g & 7) == 0 ? ~0u : 0u, o2 = (g & 3) == 0 ? ~0u : 0u, o3 = (g & 1) == 0 ? ~0u : 0u;
+        const uint32_t ownN = g == 0 ? 4u : (uint32_t)(__ffs(g) - 1);     // ancestors (depth >= Ds) whose tokens head my run
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         // the stream words of step `it` are requested one step ahead
@@ -514,23 +560,23 @@ k_decode_fine(TileArgs a)
             const uint32_t tokpos = (deadRow ? 0u : so) + inc - c;
             const uint32_t *Wp = W + (tokpos >> 4);
             nbit0 = (tokpos & 15u) * 2u;
-            nM = deadRow ? 0u : ~0u;
+            // my root exists <=> I own more tokens than the ancestors heading my run (a pruned ancestor ends the run)
+            nM = c > ownN ? ~0u : 0u;
             nw0 = Wp[0]; nw1 = Wp[1]; nw2 = Wp[2]; nw3 = Wp[3];
         };
         request(0);
         for (int it = 0; it < 16; ++it) {
-            const int S = 4 * it + (lane >> 4);
-            int V = valS[wave][S];
-            uint32_t word;
             const bool liveStep = (((uint32_t)(liveMask >> (4 * it))) & 15u) != 0u;   // wave-uniform
             const uint32_t w0 = nw0, w1 = nw1, w2 = nw2, w3 = nw3, bit0 = nbit0;
             uint32_t M = nM;                    // all ones while no ancestor is pruned (else V is final for my voxels)
             if (it + 1 < 16) request(it + 1);
-            if (!liveStep) word = (uint32_t)V * 0x01010101u;
-            else {
+            if (liveStep) {
+                const int S = 4 * it + (lane >> 4);
+                int V = (int)(tile[g * FD_TS + S] & 255u);
+                uint32_t word;
                 str[lane] = w0; str[64 + lane] = w1; str[128 + lane] = w2; str[192 + lane] = w3;
                 const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, bit0);        // my first 16 tokens
-                uint32_t cb = 0;                    // bits of my tokens consumed
+                uint32_t cb = M & (2u * ownN);      // bits of my tokens consumed: the ancestors' are done
                 // one tree token (R.cpp:783-787) where mask m is set: as a signed 2-bit field, code 1 -> +1, code 2 -> -2,
                 // code 3 -> -1, so (s + 1) >> 1 is the sign of the step and s == -1 the pruned node
                 const auto node = [&](uint32_t x, uint32_t m, int dist) {
@@ -539,23 +585,6 @@ k_decode_fine(TileArgs a)
                     M = s2 == -1 ? 0u : M;
                     cb += m & 2u;
                 };
-                uint32_t vp;
-                {   // depth Ds keeps the index value: only "pruned" and the token matter
-                    const uint32_t m = M & o0;
-                    M = (__builtin_amdgcn_sbfe((int)x0, 0, 2) & (int)m) == -1 ? 0u : M;
-                    cb = m & 2u;
-                }
-                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((M & 0xFFFFFF00u) | (uint32_t)V), 0x0010);   // from lane g & ~15
-                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
-                node(x0, M & o1, d1);
-                vp = (uint32_t)__builtin_amdgcn_ds_swizzle((int)((M & 0xFFFFFF00u) | (uint32_t)V), 0x0018);   // from lane g & ~7
-                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
-                node(x0, M & o2, d2);
-                vp = dpp_u32<0x00, 0xf>(0, (M & 0xFFFFFF00u) | (uint32_t)V);                                   // quad_perm [0,0,0,0]
-                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
-                node(x0, M & o3, d3);
-                vp = dpp_u32<0xA0, 0xf>(0, (M & 0xFFFFFF00u) | (uint32_t)V);                                   // quad_perm [0,0,2,2]
-                V = (int)(vp & 255u); M = (uint32_t)((int)vp >> 8);
                 node(x0, M, d4);                                              // my own 4-leaf subtree's root
                 const int V4 = V;
                 const uint32_t M4 = M;
@@ -589,8 +618,8 @@ k_decode_fine(TileArgs a)
                     word |= leaf(yb >> used) << 16;
                     word |= leaf(window(bit0 + cb)) << 24;
                 }
+                tile[g * FD_TS + S] = word;
             }
-            tile[g * FD_TS + S] = word;
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
