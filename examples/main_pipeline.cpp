@@ -5,6 +5,7 @@
 //   g++ -std=c++14 -O2 -Iinclude examples/main_pipeline.cpp -Lvolumerenderer_amd -lvrhip
 //       -Wl,-rpath,$PWD/volumerenderer_amd -o /tmp/main_pipeline ; /tmp/main_pipeline /tmp/bricks
 #include "vrhip/VolumeReader.hpp"
+#include "vrhip/HashedKdtree.hpp"
 #include <cmath>
 #include <cstdio>
 #include <sstream>
@@ -70,6 +71,12 @@ int main(int argc, char **argv)
     std::vector<unsigned char> t2;
     again.levelCut(again.maxTreeDepth, t2);
     std::printf("reopen: voxels equal %d\n", (int)(t2 == treeData));
+    // the third tree class keeps its interface (HashedKdtree.h:26-143); results are the VolumeKdtree path's, tolerance 4
+    HashedKdtree hashed(volume.data, volume.dataDims[0], volume.dataDims[1], volume.dataDims[2]);
+    hashed.build();
+    std::vector<unsigned char> t3;
+    hashed.levelCut(hashed.treeDepth, t3);
+    std::printf("hashed: max error %d mean %.4f\n", hashed.measureMaxError(), hashed.measureMeanError());
     brick.Unbind(); brick.Delete();
     vr_free(tex); vr_free(img);
     delete myTree;

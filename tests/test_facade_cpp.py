@@ -41,6 +41,7 @@ def test_facade_pipeline_matches_oracle(tmp_path, oracle):
     r = subprocess.run([exe, str(d)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "reopen: voxels equal 1" in r.stdout
+    assert "hashed: max error" in r.stdout          # HashedKdtree.hpp: the interface over the VolumeKdtree path
     # rebuild the same volume from the brick files the program wrote and run the oracle on it
     X, Y, Z = 64, 64, 32
     vol = np.zeros((2 * Z, 2 * Y, 2 * X), np.uint8)

@@ -469,3 +469,19 @@ def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shap
         fs.set_tree(0, ref.tree, ref.numActiveNodes, ref.distanceMap)
         assert np.array_equal(fs.decode().cpu().numpy().reshape(shape), ref.levelCut()), (case, tol, ep, "foreign")
         assert np.array_equal(fs.decode(cut_depth=D - 2).cpu().numpy().reshape(shape), ref.levelCutProgressive(D - 2))
+
+
+def test_hashed_kdtree_interface(vr, oracle):
+    """HashedKdtree keeps the reference's interface (HashedKdtree.h:26-143); parity with the reference class is
+    unpinned (it cannot run), so what is checked is that the interface delivers the VolumeKdtree path's results at
+    the class's own tolerance 4, bit-exact against the oracle, and that its error helpers agree with the oracle's."""
+    vol = rm_like((32, 32, 64), seed=11)
+    h = vr.HashedKdtree(vol.copy(), 64, 32, 32)
+    assert h.tolerance == 4
+    h.build()
+    ref = oracle.OracleTree(vol.copy(), tolerance=4, max_epochs=5).build()
+    assert np.array_equal(h.treeData, ref.tree) and list(h.distanceMap) == list(ref.distanceMap)
+    dec = h.levelCut(h.treeDepth).cpu().numpy().reshape(vol.shape)
+    assert np.array_equal(dec, ref.levelCut()) and h.queryDepth == ref.maxTreeDepth
+    assert h.measureMaxError() == oracle.measure_max_error(ref.levelCut(), vol)
+    assert h.numCollisions == 0

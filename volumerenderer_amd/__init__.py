@@ -6,12 +6,12 @@ reference's class interface, used by the parity tests and the bench."""
 from ._lib import (RENDER_COMPOSITE, RENDER_ISOSURFACE, RENDER_PARTIAL, VARIANT_GUARDED, VARIANT_MIDRANGE,
                    VARIANT_RECOVER, Camera, RenderParams, VrError)
 
-__all__ = ["BrickSet", "VolumeKdtree", "MidRangeTree", "VolumeReader", "UnitBrick", "VrError", "Camera",
+__all__ = ["BrickSet", "VolumeKdtree", "MidRangeTree", "HashedKdtree", "VolumeReader", "UnitBrick", "VrError", "Camera",
            "RenderParams"]
 
 
 def __getattr__(name):  # torch is imported lazily so that `import volumerenderer_amd` stays cheap
-    if name in ("BrickSet", "VolumeKdtree", "MidRangeTree", "measure_error", "query_error"):
+    if name in ("BrickSet", "VolumeKdtree", "MidRangeTree", "HashedKdtree", "measure_error", "query_error"):
         from . import codec
         return getattr(codec, name)
     if name in ("VolumeReader", "UnitBrick", "raycast", "default_camera", "default_params", "composite_over",

@@ -240,3 +240,28 @@ class MidRangeTree(VolumeKdtree):
 
     def convertToByteArray(self):                  # M.cpp:1095-1128
         return self._need().packed4(0)
+
+
+class HashedKdtree(VolumeKdtree):
+    """volume_renderer/HashedKdtree.h:26-227 -- the interface only; PARITY UNPINNED.
+
+    The reference class cannot be run (heap overflow on the first level, HashedKdtree.cpp:138; collision handling
+    seeded from std::random_device, :473), so there is nothing to compare with.  Callers get the same methods and
+    members over the VolumeKdtree path with the class's own tolerance (4, HashedKdtree.h:79); the hash-table members
+    exist and stay empty."""
+
+    def __init__(self, inData=None, x=0, y=0, z=0):
+        super().__init__(inData, x, y, z)
+        self.tolerance = 4
+        self.numCollisions = 0
+        self.hashMask = 0
+        self.queryDepth = 0
+
+    @property
+    def treeData(self): return self.tree
+    @property
+    def treeDepth(self): return self.maxTreeDepth
+
+    def levelCut(self, cutDepth=None, outData=None):   # HashedKdtree.h:113
+        self.queryDepth = self.treeDepth if cutDepth is None else int(cutDepth)
+        return super().levelCut(cutDepth, outData)
