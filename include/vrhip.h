@@ -124,6 +124,14 @@ vr_status vr_brickset_get_packed4(vr_brickset *bs, int32_t brick, uint8_t *dst_h
  * ancestor at depth min(cut_depth, depth of its terminal node).  Asynchronous on `stream`. */
 vr_status vr_brickset_decode(vr_brickset *bs, int32_t cut_depth, uint8_t *out_dev, void *stream);
 
+/* MidRangeTree only (new: the reference builds the half-range stream, MidRangeTree.cpp:399-544, 871-982, but
+ * never decodes it -- its levelCut, :984-1093, reads the mid stream alone): the same progressive
+ * decode applied to the range stream, i.e. per voxel the half range of its terminal node's box as the
+ * encoder reconstructed it (distanceMap_range, codes of tree_range).  With vr_brickset_decode this gives
+ * [mid - range, mid + range] bounds at any cut depth (coarse-to-fine refinement, empty-space tests).
+ * VR_ERR_STATE for other variants, VR_ERR_UNSUPPORTED for a set opened from a file. */
+vr_status vr_brickset_decode_range(vr_brickset *bs, int32_t cut_depth, uint8_t *out_dev, void *stream);
+
 /* Install a foreign preorder stream (e.g. read from a reference-written file) as
  * brick `brick`: builds the decode side-car index from the bytes alone. */
 vr_status vr_brickset_set_tree(vr_brickset *bs, int32_t brick, const uint8_t *tree_host, int64_t tree_bytes,

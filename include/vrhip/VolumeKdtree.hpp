@@ -188,6 +188,18 @@ public:
         distanceMap_range.resize((size_t)maxTreeDepth + 1);
         check(vr_brickset_get_distance_map_range(bs, 0, distanceMap_range.data(), maxTreeDepth + 1), "get_distance_map_range");
     }
+    // New: the reference builds tree_range but its levelCut (M.cpp:984-1093) never reads it.  The half
+    // range per voxel at a cut depth; with levelCut() this bounds every voxel by [mid - range, mid + range].
+    void levelCutRange(int cutDepth, std::vector<byte> &outData)
+    {
+        using namespace vrhip_detail;
+        if (!bs) throw std::runtime_error("levelCutRange(): no tree");
+        outData.resize((size_t)(X * Y * Z));
+        DeviceBuffer r;
+        r.ensure(X * Y * Z);
+        check(vr_brickset_decode_range(bs, cutDepth, (uint8_t *)r.p, nullptr), "vr_brickset_decode_range");
+        check(vr_download(outData.data(), r.p, X * Y * Z, nullptr), "vr_download");
+    }
     // save(): VolumeKdtree::save on a VR_VARIANT_MIDRANGE set writes MidRangeTree's layout (M.cpp:753-785)
     void convertToByteArray(std::vector<byte> &byteArray)      // M.cpp:1095-1128
     {

@@ -635,6 +635,19 @@ int vko_level_cut_progressive(const vko_tree *t, int cutDepth, byte *out)
     return rc;
 }
 
+/* NOT IN THE REFERENCE (MidRangeTree builds tree_range, M.cpp:399-544,871-982, but its levelCut,
+ * M.cpp:984-1093, never reads it): the progressive cut above applied to the range stream.  Both streams
+ * are emitted in lock step (same structure, same numActiveNodes), so this is the same walk over
+ * treeRange / distanceMapRange.  Oracle of vr_brickset_decode_range. */
+int vko_level_cut_range(const vko_tree *t, int cutDepth, byte *out)
+{
+    if (!t->midrange || !t->treeRange || !t->distanceMapRange) return -10;
+    vko_tree r = *t;
+    r.tree = t->treeRange;
+    r.distanceMap = t->distanceMapRange;
+    return vko_level_cut_progressive(&r, cutDepth, out);
+}
+
 /* R.cpp:386-411: error helpers.  The reference dereferences the (cleared)
  * input, C-7; here the original volume is passed explicitly. */
 int vko_measure_max_error(const byte *decoded, const byte *original, int64_t n)

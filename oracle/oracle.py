@@ -79,6 +79,8 @@ def lib():
     L.vko_level_cut.restype = C.c_int
     L.vko_level_cut_progressive.argtypes = [p, C.c_int, p]
     L.vko_level_cut_progressive.restype = C.c_int
+    L.vko_level_cut_range.argtypes = [p, C.c_int, p]
+    L.vko_level_cut_range.restype = C.c_int
     L.vko_save.argtypes = [p, C.c_char_p]
     L.vko_open.argtypes = [C.c_char_p]
     L.vko_open.restype = p
@@ -265,6 +267,15 @@ class OracleTree:
         rc = self._L.vko_level_cut_progressive(self._h, int(cutDepth), out.ctypes.data)
         if rc != 0:
             raise RuntimeError("vko_level_cut_progressive: malformed stream (%d)" % rc)
+        return out.reshape(Z, Y, X)
+
+    def levelCutRange(self, cutDepth=None):
+        """Progressive cut of MidRangeTree's range stream (not in the reference, see kdtree_oracle.c)."""
+        X, Y, Z = self.dims
+        out = np.zeros(X * Y * Z, np.uint8)
+        rc = self._L.vko_level_cut_range(self._h, int(self.maxTreeDepth if cutDepth is None else cutDepth), out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("vko_level_cut_range (%d)" % rc)
         return out.reshape(Z, Y, X)
 
     def convertToByteArray(self):

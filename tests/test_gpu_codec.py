@@ -485,3 +485,28 @@ def test_hashed_kdtree_interface(vr, oracle):
     assert np.array_equal(dec, ref.levelCut()) and h.queryDepth == ref.maxTreeDepth
     assert h.measureMaxError() == oracle.measure_max_error(ref.levelCut(), vol)
     assert h.numCollisions == 0
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 32), (16, 16, 8), (8, 16, 128)])
+def test_midrange_range_stream_decode(vr, oracle, shape):
+    """MidRangeTree's half-range stream decoded at full depth and at progressive cuts (the reference
+    builds that stream but never decodes it, so the oracle is the progressive walk applied to tree_range /
+    distanceMap_range); together with levelCut it bounds every voxel by [mid - range, mid + range]."""
+    rng = np.random.default_rng(5 + shape[2])
+    vol = rm_like(shape, seed=4) if shape[2] != 8 else rng.integers(0, 256, shape, dtype=np.uint8)
+    z, y, x = shape
+    ref = oracle.OracleTree(vol.copy(), tolerance=2, max_epochs=2, midrange=True, guarded=True).build()
+    t = vr.MidRangeTree(vol.copy(), x, y, z)
+    t.setMaxEpochs(2); t.setErrorTolerance(2)
+    t.build()
+    assert np.array_equal(t.tree_range, ref.tree_range)
+    D = ref.origTreeDepth
+    for cut in [None, D, D - 3, max(1, D - 7), 2]:
+        got = t.levelCutRange(cut).cpu().numpy().reshape(shape)
+        assert np.array_equal(got, ref.levelCutRange(cut)), cut
+    mid = t.levelCut(D - 3).cpu().numpy().reshape(shape).astype(np.int32)
+    assert np.array_equal(mid, ref.levelCutProgressive(D - 3))
+    v = vr.VolumeKdtree(vol.copy(), x, y, z)
+    v.build()
+    with pytest.raises(vr.VrError):
+        v._bs.decode_range()                           # not a MidRangeTree: VR_ERR_STATE

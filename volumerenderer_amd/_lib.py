@@ -66,6 +66,7 @@ SIGNATURES = {
     "vr_brickset_get_distance_map_range": (_I32, [_P, _I32, _P, _I32]),
     "vr_brickset_get_packed4": (_I32, [_P, _I32, _P, _I64, C.POINTER(_I64)]),
     "vr_brickset_decode": (_I32, [_P, _I32, _P, _P]),
+    "vr_brickset_decode_range": (_I32, [_P, _I32, _P, _P]),
     "vr_brickset_set_tree": (_I32, [_P, _I32, _P, _I64, _I64, _P, _I32]),
     "vr_brickset_save": (_I32, [_P, _I32, C.c_char_p]),
     "vr_brickset_open": (_I32, [C.POINTER(_P), C.c_char_p]),

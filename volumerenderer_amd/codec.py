@@ -118,6 +118,17 @@ class BrickSet:
               "vr_brickset_decode")
         return out
 
+    def decode_range(self, out=None, cut_depth=-1, stream=None):
+        """MidRangeTree sets: the half-range stream decoded like the mid stream (vr_brickset_decode_range)."""
+        if out is None:
+            out = torch.empty(self.num_bricks * self.voxels_per_brick, dtype=torch.uint8, device="cuda")
+        if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous()
+                and out.numel() == self.num_bricks * self.voxels_per_brick):
+            raise ValueError("bad output buffer")
+        check(self._L.vr_brickset_decode_range(self._h, int(cut_depth), C.c_void_p(out.data_ptr()), _stream_ptr(stream)),
+              "vr_brickset_decode_range")
+        return out
+
     def set_tree(self, brick, tree_bytes, num_active_nodes, distance_map):
         t = np.ascontiguousarray(tree_bytes, np.uint8)
         d = np.ascontiguousarray(distance_map, np.uint8)
@@ -240,6 +251,10 @@ class MidRangeTree(VolumeKdtree):
 
     def convertToByteArray(self):                  # M.cpp:1095-1128
         return self._need().packed4(0)
+
+    def levelCutRange(self, cutDepth=None, outData=None):
+        """New (the reference never decodes tree_range): the half range per voxel at a cut depth."""
+        return self._need().decode_range(outData, -1 if cutDepth is None else int(cutDepth))
 
 
 class HashedKdtree(VolumeKdtree):

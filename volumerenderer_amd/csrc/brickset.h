@@ -62,7 +62,7 @@ struct BrickSet {
 // kd_encode.hip
 int encode_launch(BrickSet *bs, const uint8_t *voxDev, hipStream_t st);
 // kd_decode.hip
-int decode_launch(BrickSet *bs, uint8_t *outDev, int cutDepth, hipStream_t st);
+int decode_launch(BrickSet *bs, uint8_t *outDev, int cutDepth, hipStream_t st, bool rangeStream = false);
 int cut_values_from_stream(BrickSet *bs, const uint8_t *treeHost, int64_t numActive, const uint8_t *dmapHost, int cut,
                            std::vector<uint8_t> &vals);
 int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *treeHost, int64_t numActive,

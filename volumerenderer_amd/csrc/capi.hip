@@ -401,6 +401,21 @@ vr_status vr_brickset_decode(vr_brickset *h, int32_t cut_depth, uint8_t *out, vo
     return VR_OK;
 }
 
+vr_status vr_brickset_decode_range(vr_brickset *h, int32_t cut_depth, uint8_t *out, void *stream)
+{
+    if (!h || !out) return VR_ERR_INVALID;
+    BrickSet &b = h->s;
+    if (!b.built) return VR_ERR_STATE;
+    if (b.variant != VR_VARIANT_MIDRANGE) return VR_ERR_STATE;
+    if (b.foreign) return VR_ERR_UNSUPPORTED;          // an opened file carries no BFS codes to seed the index scalars from
+    if (cut_depth > b.maxDepth) return VR_ERR_INVALID;
+    const int cut = cut_depth < 0 ? b.maxDepth : cut_depth;
+    if (decode_launch(&b, out, cut, (hipStream_t)stream, true) != 0) return VR_ERR_NO_DEVICE;
+    b.decodeTimingPending = true;
+    b.lastStream = stream;
+    return VR_OK;
+}
+
 vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tree, int64_t tree_bytes,
                                int64_t num_active, const uint8_t *dmap, int32_t map_len)
 {

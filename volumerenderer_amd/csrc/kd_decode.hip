@@ -661,26 +661,30 @@ k_cut_values(const uint8_t *__restrict__ codes, int64_t codeStride, const Ctrl *
     out[(int64_t)brick * nIdx + s] = (uint8_t)val;
 }
 
-int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
+int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rangeStream)
 {
     hipEventRecord(bs->ev[5], st);
-    const uint8_t *cutVals = nullptr;
-    if (cut < bs->Ds) {
+    // MidRangeTree's second stream is emitted in lock step with the first (M.cpp:871-982): same token positions,
+    // so the same side-car offsets serve it; only the scalars (its own codes, its own distanceMap) differ
+    const Stream2 &sm = rangeStream ? bs->rng : bs->mid;
+    const uint8_t *cutVals = nullptr, *idxVals = bs->idxVal;
+    if (cut < bs->Ds || rangeStream) {
         if (!bs->idxValCut) return -2;
         if (!bs->foreign)
             hipLaunchKernelGGL(k_cut_values, dim3((unsigned)((bs->nIdx + 255) / 256), bs->B), dim3(256), 0, st,
-                               bs->mid.codes, bs->codeStride, bs->mid.ctrl, bs->Ds, cut, bs->nIdx, bs->idxValCut);
+                               sm.codes, bs->codeStride, sm.ctrl, bs->Ds, cut < bs->Ds ? cut : bs->Ds, bs->nIdx, bs->idxValCut);
         cutVals = bs->idxValCut;   // foreign streams: filled by the host from the bytes (capi)
+        if (rangeStream) idxVals = bs->idxValCut;
     }
     TileArgs t;
     if (!getenv("VRHIP_DECODE_V1") && tile_geometry(bs, t)) {
-        t.tree = bs->mid.tree; t.treeCap = bs->treeCap;
-        t.idxOff = bs->idxOff; t.idxVal = bs->idxVal; t.nIdx = bs->nIdx;
-        t.ctrls = bs->mid.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
+        t.tree = sm.tree; t.treeCap = bs->treeCap;
+        t.idxOff = bs->idxOff; t.idxVal = idxVals; t.nIdx = bs->nIdx;
+        t.ctrls = sm.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
         t.cut = cut; t.idxValCut = cutVals; t.spread = bs->spread;
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
         t.fine = bs->fineIdx;
-        bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !getenv("VRHIP_DECODE_WALK");
+        bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !rangeStream && !getenv("VRHIP_DECODE_WALK");
         for (int i = 0; useFine && i < bs->B; ++i) useFine = bs->fineHas[(size_t)i] != 0;
         if (useFine)
             hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((ntiles + FD_WAVES - 1) / FD_WAVES), bs->B),
@@ -690,9 +694,9 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st)
                                dim3(64 * DEC_WAVES), 0, st, t);
     } else {
         DecodeArgs a;
-        a.tree = bs->mid.tree; a.treeCap = bs->treeCap;
-        a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
-        a.ctrls = bs->mid.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
+        a.tree = sm.tree; a.treeCap = bs->treeCap;
+        a.idxOff = bs->idxOff; a.idxVal = idxVals; a.nIdx = bs->nIdx;
+        a.ctrls = sm.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
         a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
         a.cut = cut; a.idxValCut = cutVals;
         hipLaunchKernelGGL(k_decode_lane, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
