@@ -44,6 +44,7 @@ struct BrickSet {
     uint8_t *idxValCut = nullptr; // B * nIdx  progressive cut above the index level: ancestor scalars
     uint8_t *fineIdx = nullptr;   // B * nIdx * 16  tokens owned by each 4-leaf subtree of a depth-Ds node (fused encoder only)
     std::vector<uint8_t> fineHas; // per brick: fineIdx describes its current stream (all set -> k_decode_fine)
+    uint32_t *decTables = nullptr; // B * FD_TABLE_WORDS: k_decode_fine's tables of every brick for the current cut
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
     bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream

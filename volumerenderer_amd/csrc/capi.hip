@@ -162,7 +162,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_stream2(b.rng);
     for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
     hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine); hipFree(b.chainLut);
-    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.lut); hipFree(b.spread);
+    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;
     return VR_OK;

@@ -157,6 +157,7 @@ struct TileArgs {
     const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
     const uint32_t *spread;     // BrickSet::spread (coordinate -> Morton rank bits)
     const uint8_t *fine;        // BrickSet::fineIdx (k_decode_fine only)
+    const uint32_t *tables;     // BrickSet::decTables (k_decode_fine only)
 };
 
 #define DEC_WAVES 4
@@ -445,6 +446,33 @@ __device__ __forceinline__ void leaf_table(const uint8_t *dmS, uint32_t *lutL)
     }
 }
 
+// k_decode_fine's tables depend on the brick (its distanceMap) and the cut only: built once per decode, one block
+// per brick, and copied into LDS by every block of the brick (building them in place cost each block as many
+// instructions as a fifth of its tiles).  Layout: leaf table (1024 words), branch table 2 (64), distances (16 bytes).
+#define FD_TABLE_WORDS (1024 + 64 + 4)
+
+__global__ void __launch_bounds__(256)
+k_fine_tables(const Ctrl *ctrls, int D, int Ds, int cut, uint32_t *tables)
+{
+    __shared__ uint8_t dmS[16];
+    __shared__ uint32_t lutL[1024], lutC2[64];
+    const int brick = blockIdx.x;
+    if (threadIdx.x < 16) {
+        const uint8_t *dmap = ctrls[brick].distanceMap;
+        const int t = threadIdx.x;
+        const int depth = t < 8 ? Ds + (t < 7 ? t : 0) : D + (t - 8);
+        dmS[t] = (t == 0 || depth > cut) ? 0 : dmap[depth];      // as in k_decode_tile
+    }
+    __syncthreads();
+    chain_tables(dmS, nullptr, lutC2);
+    leaf_table(dmS, lutL);
+    __syncthreads();
+    uint32_t *o = tables + (int64_t)brick * FD_TABLE_WORDS;
+    for (int i = threadIdx.x; i < 1024; i += 256) o[i] = lutL[i];
+    if (threadIdx.x < 64) o[1024 + threadIdx.x] = lutC2[threadIdx.x];
+    if (threadIdx.x < 4) o[1088 + threadIdx.x] = ((const uint32_t *)dmS)[threadIdx.x];
+}
+
 __global__ void __launch_bounds__(64 * FD_WAVES)
 k_decode_fine(TileArgs a)
 {
@@ -452,8 +480,9 @@ k_decode_fine(TileArgs a)
     __shared__ uint32_t strS[FD_WAVES][5 * 64];         // [word][lane]: my 4 stream words (+ 1 never needed but read)
     __shared__ uint32_t offS[FD_WAVES][64];             // per subtree of the tile: token offset of its root
     __shared__ uint32_t cntS[FD_WAVES][64 * 4];         // ... the 16 owned-token counts (bytes)
-    __shared__ uint8_t dmS[16];
-    __shared__ uint32_t lutL[1024], lutC2[64];
+    __shared__ uint32_t tabS[FD_TABLE_WORDS];
+    uint32_t *lutL = tabS, *lutC2 = tabS + 1024;
+    const uint8_t *dmS = (const uint8_t *)(tabS + 1088);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
     const int tileId = blockIdx.x * FD_WAVES + wave;
@@ -474,15 +503,8 @@ k_decode_fine(TileArgs a)
     const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
     // blocks whose tiles all lie in pruned regions (constant bricks, pure fluid) need no tables
     if (__syncthreads_or(liveMask != 0ull ? 1 : 0)) {
-        if (threadIdx.x < 16) {
-            const uint8_t *dmap = a.ctrls[brick].distanceMap;
-            const int t = threadIdx.x;
-            const int depth = t < 8 ? a.Ds + (t < 7 ? t : 0) : a.D + (t - 8);
-            dmS[t] = (t == 0 || depth > a.cut) ? 0 : dmap[depth];      // as in k_decode_tile
-        }
-        __syncthreads();
-        chain_tables(dmS, nullptr, lutC2);
-        leaf_table(dmS, lutL);
+        const uint32_t *tg = a.tables + (int64_t)brick * FD_TABLE_WORDS;
+        for (int i = threadIdx.x; i < FD_TABLE_WORDS; i += 64 * FD_WAVES) tabS[i] = tg[i];
         __syncthreads();
     }
     if (!tileValid) return;
@@ -686,6 +708,10 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         t.fine = bs->fineIdx;
         bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !rangeStream && !getenv("VRHIP_DECODE_WALK");
         for (int i = 0; useFine && i < bs->B; ++i) useFine = bs->fineHas[(size_t)i] != 0;
+        if (useFine && !bs->decTables && hipMalloc(&bs->decTables, (size_t)bs->B * FD_TABLE_WORDS * 4) != hipSuccess) return -3;
+        t.tables = bs->decTables;
+        if (useFine)
+            hipLaunchKernelGGL(k_fine_tables, dim3(bs->B), dim3(256), 0, st, bs->mid.ctrl, bs->D, bs->Ds, cut, bs->decTables);
         if (useFine)
             hipLaunchKernelGGL(k_decode_fine, dim3((unsigned)((ntiles + FD_WAVES - 1) / FD_WAVES), bs->B),
                                dim3(64 * FD_WAVES), 0, st, t);
