@@ -1336,6 +1336,20 @@ __device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t *shWave, uin
     return woff + incl - v;
 }
 
+// the same for a block of exactly four waves: four LDS reads, no loop over a run-time wave count
+__device__ __forceinline__ uint32_t block4_excl_scan_u32(uint32_t v, uint32_t *shWave, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_add_dpp(v);
+    if (lane == 63) shWave[w] = incl;
+    __syncthreads();
+    const uint32_t s0 = shWave[0], s1 = shWave[1], s2 = shWave[2], s3 = shWave[3];
+    __syncthreads();
+    total = s0 + s1 + s2 + s3;
+    const uint32_t woff = w == 0 ? 0u : (w == 1 ? s0 : (w == 2 ? s0 + s1 : s0 + s1 + s2));
+    return woff + incl - v;
+}
+
 // ---- prune + block-local emit (VolumeKdtree streams with D >= 12: K = 6, Ds = D-6) --------------
 // One block owns a depth-(D-12) subtree: 4096 leaves, 16 per thread.  It prunes the twelve levels
 // bottom-up like k_prune12 (the four above the leaves in registers, the other eight in LDS), and then,
@@ -1604,7 +1618,7 @@ k_prune_emit12(PruneEmitArgs a)
         if (code == 3) alive = false;
     }
     uint32_t tot;
-    const uint32_t pos = block_excl_scan_u32((uint32_t)(ns + (alive ? cnt4 : 0)), shw, tot);
+    const uint32_t pos = block4_excl_scan_u32((uint32_t)(ns + (alive ? cnt4 : 0)), shw, tot);
     uint32_t bitpos = 2u * pos;
     pe_put(W, bitpos, (unsigned long long)S, ns);
     bitpos += 2u * (uint32_t)ns;
@@ -1662,7 +1676,10 @@ k_prune_emit12(PruneEmitArgs a)
     __syncthreads();
     const uint32_t nw = (tot + 15u) >> 4;
     const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
-    for (uint32_t i = t; i < nw; i += 256) *pe_stage(stg, i) = W[i];
+    // piece by piece (three 4 KiB areas): a per-word choice between three 64-bit pointers cost more than the copy
+    for (uint32_t i = t; i < (nw < 1024u ? nw : 1024u); i += 256) stg.p0[i] = W[i];
+    if (nw > 1024u) for (uint32_t i = 1024u + t; i < (nw < 2048u ? nw : 2048u); i += 256) stg.p1[i - 1024u] = W[i];
+    if (nw > 2048u) for (uint32_t i = 2048u + t; i < nw; i += 256) stg.p2[i - 2048u] = W[i];
 }
 
 
