@@ -1677,9 +1677,12 @@ k_prune_emit12(PruneEmitArgs a)
     const uint32_t nw = (tot + 15u) >> 4;
     const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
     // piece by piece (three 4 KiB areas): a per-word choice between three 64-bit pointers cost more than the copy
-    for (uint32_t i = t; i < (nw < 1024u ? nw : 1024u); i += 256) stg.p0[i] = W[i];
-    if (nw > 1024u) for (uint32_t i = 1024u + t; i < (nw < 2048u ? nw : 2048u); i += 256) stg.p1[i - 1024u] = W[i];
-    if (nw > 2048u) for (uint32_t i = 2048u + t; i < nw; i += 256) stg.p2[i - 2048u] = W[i];
+#pragma unroll 1
+    for (uint32_t k = 0; k * 256u < nw; ++k) {          // four trips per piece: the piece is uniform in a trip
+        uint32_t *pp = k < 4u ? stg.p0 : (k < 8u ? stg.p1 : stg.p2);
+        const uint32_t i = k * 256u + t;
+        if (i < nw) pp[(k & 3u) * 256u + t] = W[i];
+    }
 }
 
 
