@@ -153,6 +153,7 @@ struct TileArgs {
     int D, Ds;
     int jx, jy, jz;          // position of each axis among the three deepest split levels (0 = deepest)
     int tilesX, tilesY, tilesZ;
+    int ltx, lty;               // log2 of tilesX, tilesY (brick extents are powers of two): tile coordinates by shifts
     int cut;                    // progressive cut depth (maxTreeDepth = the reference's levelCut)
     const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
     const uint32_t *spread;     // BrickSet::spread (coordinate -> Morton rank bits)
@@ -308,7 +309,7 @@ k_decode_tile(TileArgs a)
     chain_tables(dmS, lutC1, lutC2);
     __syncthreads();
     if (!tileValid) return;
-    const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
+    const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
 
     // ---- which subtree is mine
     const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};   // subtree coords (units of 4 voxels)
@@ -489,7 +490,7 @@ k_decode_fine(TileArgs a)
     uint32_t *tile = tileS[wave];
     uint32_t *str = strS[wave];
     const bool tileValid = tileId < a.tilesX * a.tilesY * a.tilesZ;
-    const int tx = tileId % a.tilesX, ty = (tileId / a.tilesX) % a.tilesY, tz = tileId / (a.tilesX * a.tilesY);
+    const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
     uint32_t off = VR_IDX_DEAD;
     int val0 = 0;
     uint4 cv = make_uint4(0, 0, 0, 0);
@@ -665,6 +666,9 @@ static bool tile_geometry(const BrickSet *bs, TileArgs &a)
     for (int q = 0; q < 3; ++q) pos[g.axis[D - 3 + q]] = 2 - q;   // deepest level -> rank bit 0
     a.jx = pos[0]; a.jy = pos[1]; a.jz = pos[2];
     a.tilesX = g.X / 128; a.tilesY = g.Y / 8; a.tilesZ = g.Z / 4;
+    a.ltx = 0; while ((1 << a.ltx) < a.tilesX) ++a.ltx;
+    a.lty = 0; while ((1 << a.lty) < a.tilesY) ++a.lty;
+    if ((1 << a.ltx) != a.tilesX || (1 << a.lty) != a.tilesY) return false;
     return true;
 }
 
