@@ -205,8 +205,11 @@ __device__ __forceinline__ void chain_tables(const uint8_t *dmS, uint32_t *lutC1
             LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
             HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
         }
-        const uint32_t ent = (uint32_t)(A + 256) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) |
-                             ((uint32_t)term << 29);
+        // k_decode_fine (no table 1) takes LO / HI as whole bytes: min / max read them without a separate extract
+        const uint32_t ent = lutC1 ? (uint32_t)(A + 256) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) |
+                                         ((uint32_t)term << 29)
+                                   : (uint32_t)(A + 256) | ((uint32_t)len << 10) | ((uint32_t)term << 13) | ((uint32_t)LO << 16) |
+                                         ((uint32_t)HI << 24);
         if (tb == 0) lutC1[idx] = ent; else lutC2[idx] = ent;
     }
 }
@@ -427,8 +430,8 @@ k_decode_tile(TileArgs a)
 #define FD_TS 68          // tile row stride in words: lanes (g, S) -> bank 4g + S, conflict-free
 
 // voxel-leaf table (256 threads, 1024 entries): a leaf's code and the first four tokens of its grown branch,
-// composed like chain_tables: v -> min(max(v + A, LO), HI).  [0:10) A + 512, [10:18) LO, [18:26) HI, [26:29) tokens
-// consumed (code included), 29 ended (pruned leaf or terminator; otherwise branch tokens 5-7 follow: lutC2).
+// composed like chain_tables: v -> min(max(v + A, LO), HI).  [0:10) A + 512, [10:13) tokens consumed (code included),
+// 13 ended (pruned leaf or terminator; otherwise branch tokens 5-7 follow: lutC2), byte 2 LO, byte 3 HI.
 __device__ __forceinline__ void leaf_table(const uint8_t *dmS, uint32_t *lutL)
 {
     for (int idx = threadIdx.x; idx < 1024; idx += 256) {
@@ -443,7 +446,7 @@ __device__ __forceinline__ void leaf_table(const uint8_t *dmS, uint32_t *lutL)
             LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
             HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
         }
-        lutL[idx] = (uint32_t)(A + 512) | ((uint32_t)LO << 10) | ((uint32_t)HI << 18) | ((uint32_t)len << 26) | ((uint32_t)term << 29);
+        lutL[idx] = (uint32_t)(A + 512) | ((uint32_t)len << 10) | ((uint32_t)term << 13) | ((uint32_t)LO << 16) | ((uint32_t)HI << 24);
     }
 }
 
@@ -618,10 +621,10 @@ k_decode_fine(TileArgs a)
                 // one voxel leaf: its code + grown branch at the low end of y (R.cpp:655-704 as the decoder sees it)
                 const auto leaf = [&](uint32_t y) {
                     const uint32_t e1 = lutL[y & 1023u], e2 = lutC2[(y >> 10) & 63u];
-                    const int b1 = med3i(V + (int)(e1 & 1023u) - 512, (int)((e1 >> 10) & 255u), (int)((e1 >> 18) & 255u));
-                    const int b2 = med3i(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 10) & 255u), (int)((e2 >> 18) & 255u));
-                    const bool ended = ((e1 >> 29) & 1u) != 0u;
-                    const uint32_t len = ((e1 >> 26) & 7u) + (ended ? 0u : ((e2 >> 26) & 7u));
+                    const int b1 = min(max(V + (int)(e1 & 1023u) - 512, (int)((e1 >> 16) & 255u)), (int)(e1 >> 24));
+                    const int b2 = min(max(b1 + (int)(e2 & 1023u) - 256, (int)((e2 >> 16) & 255u)), (int)(e2 >> 24));
+                    const bool ended = ((e1 >> 13) & 1u) != 0u;
+                    const uint32_t len = ((e1 >> 10) & 7u) + (ended ? 0u : ((e2 >> 10) & 7u));
                     cb += (2u * len) & M;
                     const int v = ended ? b1 : b2;
                     return (uint32_t)(M ? v : V);
