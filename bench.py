@@ -106,8 +106,8 @@ def make_volume_gpu(torch, gdims, bdims, seed, kind="rm_volume"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--volume", type=int, nargs=3, default=[2048, 2048, 1920], help="global volume per GPU")
     ap.add_argument("--dims", type=int, nargs=3, default=[256, 256, 128], help="brick dims (main.cpp:78)")
     ap.add_argument("--bricks", type=int, default=0, help="use only the first N bricks (0 = whole volume)")
