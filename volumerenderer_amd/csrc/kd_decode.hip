@@ -477,13 +477,12 @@ k_fine_tables(const Ctrl *ctrls, int D, int Ds, int cut, uint32_t *tables)
     if (threadIdx.x < 4) o[1088 + threadIdx.x] = ((const uint32_t *)dmS)[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(64 * FD_WAVES)
+__global__ void __launch_bounds__(64 * FD_WAVES, 6)
 k_decode_fine(TileArgs a)
 {
     __shared__ uint32_t tileS[FD_WAVES][16 * FD_TS];    // [leaf / 4][subtree]
-    __shared__ uint32_t strS[FD_WAVES][5 * 64];         // [word][lane]: my 4 stream words (+ 1 never needed but read)
+    __shared__ uint32_t strS[FD_WAVES][4 * 64];         // [word][lane]: my 4 stream words
     __shared__ uint32_t offS[FD_WAVES][64];             // per subtree of the tile: token offset of its root
-    __shared__ uint32_t cntS[FD_WAVES][64 * 4];         // ... the 16 owned-token counts (bytes)
     __shared__ uint32_t tabS[FD_TABLE_WORDS];
     uint32_t *lutL = tabS, *lutC2 = tabS + 1024;
     const uint8_t *dmS = (const uint8_t *)(tabS + 1088);
@@ -515,7 +514,6 @@ k_decode_fine(TileArgs a)
     if (liveMask == 0ull) tile[lane] = (uint32_t)val0 * 0x01010101u;      // as in k_decode_tile
     else {
         offS[wave][lane] = off;
-        *(uint4 *)&cntS[wave][lane * 4] = cv;
         const int d1 = dmS[1], d2 = dmS[2], d3 = dmS[3], d4 = dmS[4], d5 = dmS[5];
         const uint8_t *TB = a.tree + (int64_t)brick * a.treeCap;
         const uint32_t *W = (const uint32_t *)TB;
@@ -564,19 +562,23 @@ k_decode_fine(TileArgs a)
                 step(v3[i], a3[i], x[i] >> (i == 0 ? 6 : (i == 4 ? 4 : ((i & 1) ? 0 : 2))), d3);
             }
 #pragma unroll
-            for (int gg = 0; gg < 16; ++gg) tile[gg * FD_TS + lane] = (uint32_t)v3[gg >> 1] * 0x01010101u;
+            // (+ the subtree's count, XORed into byte 1: zero for every subtree whose word is already final)
+            for (int gg = 0; gg < 16; ++gg)
+                tile[gg * FD_TS + lane] = ((uint32_t)v3[gg >> 1] * 0x01010101u) ^ (((cw[gg >> 2] >> ((gg & 3) * 8)) & 255u) << 8);
         }
         const int g = lane & 15;
         const uint32_t ownN = g == 0 ? 4u : (uint32_t)(__ffs(g) - 1);     // ancestors (depth >= Ds) whose tokens head my run
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         // the stream words of step `it` are requested one step ahead
-        uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nbit0 = 0, nM = 0;
+        uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nbit0 = 0, nM = 0, nV = 0;
         const auto request = [&](int it) {
             if ((((uint32_t)(liveMask >> (4 * it))) & 15u) == 0u) return;       // wave-uniform
             const int S = 4 * it + (lane >> 4);
             const uint32_t so = offS[wave][S];
-            const uint32_t c = ((const uint8_t *)cntS[wave])[S * 16 + g];
+            const uint32_t tw = tile[g * FD_TS + S];            // parked by the per-tile pass: scalar and count
+            const uint32_t c = ((tw >> 8) ^ tw) & 255u;
+            nV = tw & 255u;
             uint32_t inc = c;                                   // prefix sum within the row of 16 lanes
             inc += dpp_u32<0x111, 0xf>(0, inc);
             inc += dpp_u32<0x112, 0xf>(0, inc);
@@ -595,10 +597,10 @@ k_decode_fine(TileArgs a)
             const bool liveStep = (((uint32_t)(liveMask >> (4 * it))) & 15u) != 0u;   // wave-uniform
             const uint32_t w0 = nw0, w1 = nw1, w2 = nw2, w3 = nw3, bit0 = nbit0;
             uint32_t M = nM;                    // all ones while no ancestor is pruned (else V is final for my voxels)
+            int V = (int)nV;
             if (it + 1 < 16) request(it + 1);
             if (liveStep) {
                 const int S = 4 * it + (lane >> 4);
-                int V = (int)(tile[g * FD_TS + S] & 255u);
                 uint32_t word;
                 str[lane] = w0; str[64 + lane] = w1; str[128 + lane] = w2; str[192 + lane] = w3;
                 const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, bit0);        // my first 16 tokens
@@ -616,7 +618,8 @@ k_decode_fine(TileArgs a)
                 const uint32_t M4 = M;
                 const auto window = [&](uint32_t bp) {      // 16 tokens from bit bp of my words
                     const uint32_t k = bp >> 5;
-                    return __builtin_amdgcn_alignbit(str[(k + 1) * 64 + lane], str[k * 64 + lane], bp & 31u);
+                    // (bits past my fourth word are never part of a token of mine: any word will do there)
+                    return __builtin_amdgcn_alignbit(str[min(k + 1u, 3u) * 64 + lane], str[k * 64 + lane], bp & 31u);
                 };
                 // one voxel leaf: its code + grown branch at the low end of y (R.cpp:655-704 as the decoder sees it)
                 const auto leaf = [&](uint32_t y) {
