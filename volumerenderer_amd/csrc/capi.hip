@@ -256,7 +256,10 @@ vr_status vr_brickset_build(vr_brickset *h, const uint8_t *vox, void *stream)
     b.hostCtrlValid = false;
     b.foreign = false;
     std::fill(b.openTreeBytes.begin(), b.openTreeBytes.end(), -1);
-    if (encode_launch(&b, vox, (hipStream_t)stream) != 0) return VR_ERR_NO_DEVICE;
+    {   // -3: a lazily allocated side buffer did not fit
+        const int rc = encode_launch(&b, vox, (hipStream_t)stream);
+        if (rc != 0) return rc == -3 ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
+    }
     b.built = true;
     b.timingsPending = true;
     b.lastStream = stream;
@@ -395,7 +398,10 @@ vr_status vr_brickset_decode(vr_brickset *h, int32_t cut_depth, uint8_t *out, vo
             HIPCHK(hipMemcpy(b.idxValCut + (size_t)br * b.nIdx, vals.data(), vals.size(), hipMemcpyHostToDevice));
         }
     }
-    if (decode_launch(&b, out, cut, (hipStream_t)stream) != 0) return VR_ERR_NO_DEVICE;
+    {
+        const int rc = decode_launch(&b, out, cut, (hipStream_t)stream);
+        if (rc != 0) return rc == -3 ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
+    }
     b.decodeTimingPending = true;
     b.lastStream = stream;
     return VR_OK;
