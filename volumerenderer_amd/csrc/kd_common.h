@@ -94,6 +94,12 @@ typedef short vr_s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short vr_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ vr_s16x2 pk_s(uint32_t v) { return __builtin_bit_cast(vr_s16x2, v); }
 __device__ __forceinline__ uint32_t pk_u(vr_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ vr_s16x2 pk_mad(vr_s16x2 a, vr_s16x2 b, vr_s16x2 c)
+{   // a * b + c per 16-bit lane in one instruction (the compiler prefers shift + add for small constant factors)
+    vr_s16x2 r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ vr_s16x2 pk_abs(vr_s16x2 x) { return __builtin_elementwise_max(x, (vr_s16x2)(0) - x); }
 __device__ __forceinline__ uint32_t pk_sumsq(vr_s16x2 e, uint32_t acc)
 {

@@ -434,14 +434,15 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         const vr_s16x2 Th2 = pk_s((uint32_t)Th * 0x10001u), w2 = pk_s((uint32_t)(2 * Th) * 0x10001u);
         // per chain: low = 2*Th*cc - s, and the extremes of low / low + 2cc over the positions BEFORE each node
         vr_s16x2 low = (vr_s16x2)(0), cc = (vr_s16x2)(0), amax = (vr_s16x2)(0), bmin = (vr_s16x2)(0);
+        const vr_s16x2 two2 = pk_s(0x00020002u);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const vr_s16x2 dm = (__builtin_elementwise_min(Th2, h[k]) - pd[k]) >> 15;     // -1 where the node counts
-            low += pk_s(pk_u(dm) & pk_u(w2 - pd[k]));
+            low = dm * (pd[k] - w2) + low;          // += 2 Th - pd where it counts (v_pk_mad_i16)
             cc -= dm;
             if (k < 7) {
                 amax = __builtin_elementwise_max(amax, low);
-                bmin = __builtin_elementwise_min(bmin, low + cc + cc);
+                bmin = __builtin_elementwise_min(bmin, pk_mad(cc, two2, low));
             }
         }
         const int low1 = low.x, low2 = low.y, cc1 = cc.x, cc2 = cc.y;
