@@ -658,8 +658,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
         const uint32_t take = pk_u((ax - c.pd) >> 15);                 // 0xFFFF per lane where |x| < pd
         const uint32_t code2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));   // up ? 1 : 2 (per-lane wrap)
         if (j < 4) wa |= code2 << (4 * j); else wb |= code2 << (4 * (j - 4));
-        const uint32_t dn = ~c.up;
-        const vr_s16x2 r = c.T2 + (pk_s(pk_u(x) ^ dn) - pk_s(dn));    // up ? t + x : t - x
+        const vr_s16x2 r = pk_mad(x, pk_mad(pk_s(c.up), pk_s(0xFFFEFFFEu), pk_s(0xFFFFFFFFu)), c.T2);   // up ? t + x : t - x  (sign = -2 up - 1)
         const uint32_t rec = (take & pk_u(r)) | (~take & pk_u(c.P2));
         if (j & 1) rw[j >> 1] = __builtin_amdgcn_perm(rec, rprev, 0x06040200u); else rprev = rec;
         if (needDF) {
