@@ -419,13 +419,18 @@ k_decode_tile(TileArgs a)
 }
 
 // ---- fine tile decode -----------------------------------------------------------------
-// Same tile, same gather, but ONE LANE PER FOUR VOXELS and no walk: the fused encoder leaves, next to the
-// depth-Ds index, how many tokens every 4-leaf subtree owns in preorder (its 7 nodes, their grown branches, and
-// the ancestors down from depth Ds whose first leaf is its first leaf).  A DPP row (16 lanes) takes one depth-Ds
-// subtree: a row prefix sum of the counts gives every lane its token offset, the owned ancestors are resolved
-// top-down in four steps (owner decodes, ds_swizzle / quad_perm broadcast value + "pruned" to the lanes below),
-// and then each lane decodes its own 7 nodes as straight-line predicated code -- at most 43 tokens, held in four
-// registers staged through LDS for the bit-addressed lookahead.  16 such steps fill the wave's 64-subtree tile.
+// Same tile, same gather, but ONE LANE PER FOUR VOXELS and no walk: next to the depth-Ds index there is, for every
+// 4-leaf subtree, the number of tokens it owns in preorder (its 7 nodes, their grown branches, and the ancestors down
+// from depth Ds whose first leaf is its first leaf): from the fused encoder, or from the host parse of a foreign stream.
+//   per tile   one lane per depth-Ds subtree decodes its 15 nodes of depths Ds .. Ds+3 (their tokens head the runs of
+//              the even 4-leaf subtrees: prefix sums of the 16 counts, eight unaligned dword loads) and parks, in the
+//              tile word of each 4-leaf subtree, the scalar it hangs from (replicated: already final where an
+//              ancestor is pruned) with its count XORed into byte 1;
+//   16 steps   a DPP row (16 lanes) takes one depth-Ds subtree, four of them per step: a row prefix sum of the counts
+//              gives every lane its token offset, its four stream words arrive one step ahead, and it decodes its own
+//              7 nodes as straight-line predicated code (at most 39 + 4 tokens, staged through LDS for the
+//              bit-addressed lookahead; a voxel leaf with its grown branch is two table lookups);
+//   gather     as in k_decode_tile.
 #define FD_WAVES 4
 #define FD_TS 68          // tile row stride in words: lanes (g, S) -> bank 4g + S, conflict-free
 
