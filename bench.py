@@ -8,8 +8,11 @@ Workload (BASELINE.json metric): one 2048x2048x1920 uint8 volume = the reference
 grid of 256x256x128 bricks (main.cpp:78-79), one kd-tree per brick, all 960 trees built and
 decoded by one batched launch sequence.  A "step" = build() + levelCut() of the whole
 volume (+ one 1080p ray-cast frame of the decoded volume, timed separately).
-N > 1 (torch.distributed.run, one rank per GPU): bricks / timesteps shard with no data-path
-collective -- every rank encodes+decodes its own timestep of the volume (weak scaling).
+N > 1: one rank per GPU over RCCL; bricks / timesteps shard with no data-path collective --
+every rank encodes+decodes its own timestep of the volume (weak scaling).  Launched either by
+torch.distributed.run (RANK / WORLD_SIZE in the environment) or plainly as `python bench.py
+--gpus N`: the parent then starts the N ranks itself, before it touches the GPU, and relays
+rank 0's JSON line.
 """
 import argparse
 import json
@@ -24,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_TRAFFIC = "profiles/r02_pmc_hbm_traffic.json"   # separate rocprofv3 --pmc passes of this same command (profiles/refresh_profiles.sh)
 
 
 def make_bricks(kind, n_bricks, dims, seed=12345):
@@ -103,6 +107,103 @@ def make_volume_gpu(torch, gdims, bdims, seed, kind="rm_volume"):
     return out.reshape(I * J * K, Z, Y, X)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1) as a child process and pass its output and exit code on."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """VRHIP_BENCH_DRYRUN=1: the launch / rendezvous / reduction plumbing of an N-rank run with no GPU work
+    (CPU test of `--gpus N`; gloo).  Prints the contract line with value null."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "Mvoxels/s kd-tree compress+decode", "value": None, "unit": "Mvoxels/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "max_rank_seconds": round(dt, 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_baseline(vox4, B, V, tolerance, max_epochs, seconds):
+    """The CPU oracle (the reference's algorithm restated, kind "port") timed on this box's host cores on a bounded
+    sample of the same bricks: one thread (the reference's effective parallelism: COMPRESS / CONVERT / levelCut are
+    serial, R.cpp:242,293,631,726) and all usable cores with brick-level parallelism (ctypes releases the GIL)."""
+    import threading
+    from oracle import oracle as O
+    O.lib()
+    mid = B // 2                                           # bricks around the interface: the representative ones
+    cand = [(mid + (q + 1) // 2 * (1 if q % 2 else -1)) % B for q in range(B)]
+
+    def one(hb):
+        t = O.OracleTree(hb, tolerance=tolerance, max_epochs=max_epochs).build()
+        t.levelCut()
+
+    n1, t1 = 0, 0.0
+    while t1 < seconds * 0.4 and n1 < B:
+        hb = vox4[cand[n1]].cpu().numpy()
+        c0 = time.perf_counter()
+        one(hb)
+        t1 += time.perf_counter() - c0
+        n1 += 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    per_brick = t1 / max(1, n1)
+    # enough bricks to keep every thread busy for the remaining budget, fetched before the clock starts
+    want = max(cores, min(B, int(cores * max(1.0, seconds * 0.6 / max(per_brick, 1e-3)))))
+    want = min(want, B, 8 * cores)
+    host = [vox4[cand[q % B]].cpu().numpy() for q in range(want)]
+    nxt = [0]
+    lock = threading.Lock()
+
+    def worker():
+        while True:
+            with lock:
+                q = nxt[0]
+                nxt[0] += 1
+            if q >= len(host):
+                return
+            one(host[q])
+
+    th = [threading.Thread(target=worker) for _ in range(cores)]
+    c0 = time.perf_counter()
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    tall = time.perf_counter() - c0
+    return {"value": round(n1 * V / t1 / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": "%d bricks from the middle of the volume, serial build(false)+levelCut of the CPU oracle, "
+                      "1 thread, %.1f s" % (n1, t1),
+            "host_cores": os.cpu_count(), "usable_cores": cores,
+            "all_cores": {"value": round(len(host) * V / tall / 1e6, 3), "unit": "Mvoxels/s", "threads_used": cores,
+                          "sample": "%d bricks, one oracle tree per thread at a time, %.1f s wall" % (len(host), tall)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,10 +215,9 @@ def main():
     ap.add_argument("--kind", default="rm_volume")
     ap.add_argument("--tolerance", type=int, default=1)      # main.cpp:254
     ap.add_argument("--max-epochs", type=int, default=2)     # main.cpp:253
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true")
-    ap.add_argument("--groups", type=int, default=1, help="pipeline 2: independent brick groups (streams) per step")
     ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
                     help="bricksets in flight.  3 (default, ~65 GB each of the 288 GB): two build streams and a decode "
                          "stream -- the levelCut of step k and the build of step k+1 run beside the build of step k+2 "
@@ -128,15 +228,25 @@ def main():
                          "collective that fails on one rank must never hang the headline measurement)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as children (torch.distributed.run) BEFORE this
+        # process initialises HIP -- a process that holds the GPU must neither exec nor fork workers
+        sys.exit(spawn_ranks(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    # VRHIP_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box (every rank on device 0, gloo)
+    rehearsal = os.environ.get("VRHIP_BENCH_REHEARSAL") == "1"
+    if os.environ.get("VRHIP_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
+
     import __graft_entry__ as g
     g.build()                      # before anything touches the GPU (a rebuild execs hipcc)
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # VRHIP_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a one-GPU box (every rank on device 0, gloo)
-    rehearsal = os.environ.get("VRHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)
@@ -163,38 +273,28 @@ def main():
     B = vox4.shape[0]
     vox = vox4.reshape(-1)                                      # inputs resident in HBM before timing
     out = torch.empty_like(vox)
-    bs = vr.BrickSet(B, bdims, args.tolerance, args.max_epochs)
-    # pipeline >= 2: several bricksets in flight (see run_steps).  `groups` > 1 additionally deals the bricks to
-    # independent brickset groups with their own streams (measured: no gain, default 1).
-    G = max(1, min(args.groups, B)) if args.pipeline >= 2 else 1
-    cuts = [B * g // G for g in range(G + 1)]
-    gvox = [vox[cuts[g] * V:cuts[g + 1] * V] for g in range(G)]
-    gout = [out[cuts[g] * V:cuts[g + 1] * V] for g in range(G)]
-    NS = args.pipeline                 # bricksets per group
-    gsets = []
-    if NS >= 2:
+    # pipeline >= 2: several bricksets in flight (see run_steps); the serial per-kernel pass below reuses the
+    # first of them, so no further set (65 GB at the full volume) is allocated after the pipelined ones
+    NS = args.pipeline                 # bricksets in flight
+    sets = []
+    while True:
         try:
-            gsets = [[vr.BrickSet(cuts[g + 1] - cuts[g], bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
-                     for g in range(G)]
-            for g in range(G):         # setup, not a step: allocate and first-touch every set's buffers
-                for s_ in gsets[g]:
-                    s_.build(gvox[g]); s_.decode(gout[g])
+            sets = [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
+            for s_ in sets:            # setup, not a step: allocate and first-touch every set's buffers
+                s_.build(vox); s_.decode(out)
             torch.cuda.synchronize()
+            break
         except vr.VrError:             # out of device memory: one set less
-            if NS == 2:
+            if NS == 1:
                 raise
-            gsets = []
+            sets = []
             torch.cuda.synchronize()
-            NS = 2
-            gsets = [[vr.BrickSet(cuts[g + 1] - cuts[g], bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
-                     for g in range(G)]
-            for g in range(G):
-                for s_ in gsets[g]:
-                    s_.build(gvox[g]); s_.decode(gout[g])
-            torch.cuda.synchronize()
-    NB = max(1, NS - 1)                # build streams per group
-    s_build = [[torch.cuda.Stream() for _ in range(NB)] for _ in range(G)]
-    s_dec = [torch.cuda.Stream() for _ in range(G)]
+            torch.cuda.empty_cache()
+            NS -= 1
+    bs = sets[0]
+    NB = max(1, NS - 1)                # build streams
+    s_build = [torch.cuda.Stream() for _ in range(NB)]
+    s_dec = torch.cuda.Stream()
 
     def run_steps(n):
         """n x (build + levelCut) of the whole volume; every launch of every step is inside the caller's timed
@@ -206,18 +306,19 @@ def main():
                 bs.build(vox)
                 bs.decode(out)
             return
-        decoded = [[None] * NS for _ in range(G)]
+        decoded = [None] * NS
         for k in range(n):
             i = k % NS
-            for g in range(G):
-                sb = s_build[g][k % NB]
-                if decoded[g][i] is not None:
-                    sb.wait_event(decoded[g][i])
-                gsets[g][i].build(gvox[g], stream=sb)
-                built = torch.cuda.Event(); built.record(sb)
-                s_dec[g].wait_event(built)
-                gsets[g][i].decode(gout[g], stream=s_dec[g])
-                decoded[g][i] = torch.cuda.Event(); decoded[g][i].record(s_dec[g])
+            sb = s_build[k % NB]
+            if decoded[i] is not None:
+                sb.wait_event(decoded[i])
+            sets[i].build(vox, stream=sb)
+            built = torch.cuda.Event(); built.record(sb)
+            s_dec.wait_event(built)
+            sets[i].decode(out, stream=s_dec)
+            decoded[i] = torch.cuda.Event(); decoded[i].record(s_dec)
+        for st_ in s_build + [s_dec]:              # the default stream (serial pass below) follows the pipelined steps
+            torch.cuda.current_stream().wait_stream(st_)
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
@@ -266,7 +367,7 @@ def main():
     # --pmc WRITE_SIZE runs of this same command, profiles/): only quoted when the workload is the profiled one
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
         if args.kind == "rm_volume" and not args.bricks and gdims == (2048, 2048, 1920) and bdims == (256, 256, 128) \
                 and args.tolerance == 1 and args.max_epochs == 2:
             traffic = pm["decode_traffic_bytes_per_launch"]
@@ -274,7 +375,7 @@ def main():
         pass
     roofline = {"bound": "hbm", "kernel": "k_decode_fine", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic.json (bytes per launch)" if traffic else None,
+                "traffic_source": PMC_TRAFFIC + " (bytes per launch)" if traffic else None,
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(dec_avg_s * 1e3, 4)}
 
     res = {"metric": "Mvoxels/s kd-tree compress+decode", "value": round(value, 2), "unit": "Mvoxels/s",
@@ -352,20 +453,7 @@ def main():
             res["composited_1080p_error"] = repr(ex)[:200]
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import oracle as O                         # CPU baseline leg: the oracle as the reference's port
-        n_done, t_cpu = 0, 0.0
-        mid = B // 2                                           # bricks around the interface: the representative ones
-        cand = [mid + (q // 2) * (1 if q % 2 == 0 else -1) for q in range(B)]
-        while t_cpu < args.cpu_seconds and n_done < B:
-            hb = vox4[cand[n_done] % B].cpu().numpy()
-            c0 = time.perf_counter()
-            t = O.OracleTree(hb, tolerance=args.tolerance, max_epochs=args.max_epochs).build()
-            t.levelCut()
-            t_cpu += time.perf_counter() - c0
-            n_done += 1
-        res["cpu_baseline"] = {"value": round(n_done * V / t_cpu / 1e6, 3), "unit": "Mvoxels/s", "cores": 1,
-                               "kind": "port", "sample": "%d bricks from the middle of the volume, serial build(false)+"
-                               "levelCut of the CPU oracle, 1 thread, %.1f s" % (n_done, t_cpu)}
+        res["cpu_baseline"] = cpu_baseline(vox4, B, V, args.tolerance, args.max_epochs, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -72,6 +72,11 @@ typedef struct vr_tree_info {
     int32_t max_error_before;    /* encoder's own leaf max error before branch growth (R.cpp:71-76) */
     int32_t max_error_after;     /* ... after branch growth (R.cpp:115-120)        */
     double  mean_l1_after;       /* (R.cpp:122-129)                                */
+    int32_t zero_run_rewrites;   /* grown branches that ended on an evaluated "keep": the reference rewrites such a run
+                                  * of zeros to 3s (R.cpp:662-669,686-688).  Provably impossible for tolerance >= 0, so
+                                  * the GPU emitters count instead of rewriting; anything but 0 here means the stream
+                                  * differs from the reference's */
+    int32_t reserved;
 } vr_tree_info;
 
 /* ---- library / device ------------------------------------------------------- */
@@ -161,7 +166,9 @@ vr_status vr_query_error(const uint8_t *decoded_dev, const uint8_t *original_dev
 /* ---- ingest: VolumeReader<T>::LoadBricksToTexture (VolumeReader.h:151-223) ------
  * Places brick b (brick_dims, x-fastest, contiguous at bricks_dev + b*brick_voxels)
  * at grid cell brick_ijk[3*b..3*b+2] of a global x-fastest volume of
- * (I*X, J*Y, K*Z) voxels.  64-bit indices (the reference's 32-bit ones wrap above
+ * (I*X, J*Y, K*Z) voxels: volume_dev must hold I*J*K*X*Y*Z bytes whatever num_bricks is (grid cells
+ * without a brick are left untouched; the reference sizes its array by numBricks, VolumeReader.h:163-168,
+ * and overruns it for sparse brick lists -- not reproduced).  64-bit indices (the reference's 32-bit ones wrap above
  * 2^32 voxels, VolumeReader.h:171).  vr_disassemble_bricks is the inverse (global
  * volume -> contiguous bricks), used to feed per-brick trees. */
 vr_status vr_assemble_bricks(const uint8_t *bricks_dev, int32_t num_bricks, const int64_t brick_dims[3],

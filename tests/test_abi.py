@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(L):
 
 def test_struct_layouts_match_header():
     from volumerenderer_amd import _lib
-    assert C.sizeof(_lib.TreeInfo) == 80
+    assert C.sizeof(_lib.TreeInfo) == 88
     assert C.sizeof(_lib.Camera) == 48
     assert C.sizeof(_lib.RenderParams) == 32 + 24 + 48 + 8
 

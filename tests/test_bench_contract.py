@@ -30,3 +30,27 @@ def test_bench_prints_one_contract_line(pipeline):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["host_cores"] >= 1 and cb["all_cores"]["threads_used"] >= 1 and cb["all_cores"]["value"] > 0
+
+
+def test_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks itself (torch.distributed.run on
+    127.0.0.1) before touching a GPU.  VRHIP_BENCH_DRYRUN=1 keeps the ranks off the GPU (gloo), so the launch,
+    rendezvous and max-over-ranks plumbing runs on the CPU."""
+    env = dict(os.environ, VRHIP_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["dry_run"] is True
+    assert j["max_rank_seconds"] >= 0.02          # the slower rank's time (MAX over ranks)
+
+
+def test_gpus_flag_must_match_world_size():
+    env = dict(os.environ, VRHIP_BENCH_DRYRUN="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=120, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

@@ -38,6 +38,9 @@ def check_case(vr, O, vol, tol, ep, variant=0):
     assert info["num_active_nodes"] == ref.numActiveNodes
     assert np.array_equal(bs.tree(0), ref.tree)
     assert info["num_reverts"] == ref.numReverts
+    # the zero-run rewrite (R.cpp:662-669,686-688): the oracle implements and counts it, the GPU emitters only count
+    # the branches that would need it -- both must say "never" (a non-zero count would mean diverging streams)
+    assert info["zero_run_rewrites"] == 0 and ref.zeroRunRewrites == 0
     st = ref.leaf_stats()
     assert info["max_error_before"] == st["max_before"] and info["max_error_after"] == st["max_after"]
     assert abs(info["mean_l1_after"] - st["l1_after"]) < 1e-12
@@ -510,3 +513,29 @@ def test_midrange_range_stream_decode(vr, oracle, shape):
     v.build()
     with pytest.raises(vr.VrError):
         v._bs.decode_range()                           # not a MidRangeTree: VR_ERR_STATE
+
+
+def test_encoder_out_of_memory_is_reported_every_time(vr):
+    """A brickset whose stream buffers fit but whose encoder side buffers do not: build() must return
+    VR_ERR_OOM -- on every call (a half-allocated set once launched kernels on null buffers the second time) --
+    and a set that does fit must still work afterwards."""
+    import torch
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    dims = (256, 256, 128)
+    V = dims[0] * dims[1] * dims[2]
+    B = int(free // (6 * V))                 # input V + create() ~2.4 V per brick fit; the encoder's ~5.6 V more do not
+    vox = torch.zeros(B * V, dtype=torch.uint8, device="cuda")
+    bs = vr.BrickSet(B, dims, 1, 2)
+    for _ in range(2):
+        with pytest.raises(vr.VrError) as ei:
+            bs.build(vox)
+        assert ei.value.status == -3        # VR_ERR_OOM
+    del vox
+    del bs
+    torch.cuda.synchronize()
+    small = vr.BrickSet(1, (32, 32, 32), 1, 2)
+    v = np.random.default_rng(5).integers(0, 256, (32, 32, 32), dtype=np.uint8)
+    small.build(v)
+    assert small.info(0)["num_active_nodes"] > 0

@@ -51,6 +51,8 @@ struct BrickSet {
     uint32_t *spread = nullptr;  // rank bits of every x, y, z coordinate: rank(x,y,z) = spread[x] | spread[X+y] | spread[X+Y+z]
 
     std::vector<Ctrl> hostCtrl; // copied back lazily
+    uint32_t lutZeroRun = 0;    // chainLut[256]: table entries that would need the zero-run rewrite (always 0)
+    bool encoderReady = false;  // every buffer of ensure_encoder_buffers (capi.hip) is allocated
     bool built = false, hostCtrlValid = false;
     bool foreign = false;       // stream installed by set_tree/open (no encoder state)
     std::vector<int64_t> openTreeBytes; // per brick: tree.bits size as the reference's open() would have it

@@ -120,9 +120,23 @@ static vr_status alloc_stream2(BrickSet &b, Stream2 &s, bool encoder)
     return VR_OK;
 }
 
-static vr_status ensure_encoder_buffers(BrickSet &b)
+// everything ensure_encoder_buffers allocates (an opened MidRangeTree file owns rng.ctrl / rng.tree: kept)
+static void free_encoder_buffers(BrickSet &b)
 {
-    if (b.mid.temp) return VR_OK;
+    auto drop = [](auto *&p) { if (p) hipFree(p); p = nullptr; };
+    Stream2 *ss[2] = {&b.mid, &b.rng};
+    for (Stream2 *s : ss) {
+        drop(s->temp); drop(s->codes);
+        for (int i = 0; i < 3; ++i) drop(s->recon[i]);
+    }
+    for (int i = 0; i < 2; ++i) { drop(b.mmMin[i]); drop(b.mmMax[i]); }
+    drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine);
+    drop(b.chainLut); drop(b.blockTot); drop(b.blockOff);
+    b.encoderReady = false;
+}
+
+static vr_status alloc_encoder_buffers(BrickSet &b)
+{
     const size_t B = (size_t)b.B;
     HIPCHK(hipMalloc(&b.mid.temp, B * (size_t)b.heapStride));
     HIPCHK(hipMalloc(&b.mid.codes, B * (size_t)b.codeStride));
@@ -148,9 +162,21 @@ static vr_status ensure_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.blockAlive, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockVal, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockSpine, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&b.chainLut, 256 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&b.chainLut, 260 * sizeof(uint32_t)));   // 256 entries + [256]: entries that would need the zero-run rewrite
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
+    return VR_OK;
+}
+
+// "ready" is a flag of its own, set after the last allocation: a failure part-way (out of memory) releases what
+// was taken, so the next build retries from scratch and reports the same error instead of launching kernels on
+// null side buffers.
+static vr_status ensure_encoder_buffers(BrickSet &b)
+{
+    if (b.encoderReady) return VR_OK;
+    const vr_status rc = alloc_encoder_buffers(b);
+    if (rc != VR_OK) { (void)hipGetLastError(); free_encoder_buffers(b); return rc; }
+    b.encoderReady = true;
     return VR_OK;
 }
 
@@ -158,10 +184,9 @@ vr_status vr_brickset_destroy(vr_brickset *h)
 {
     if (!h) return VR_OK;
     BrickSet &b = h->s;
+    free_encoder_buffers(b);
     free_stream2(b.mid);
     free_stream2(b.rng);
-    for (int i = 0; i < 2; ++i) { hipFree(b.mmMin[i]); hipFree(b.mmMax[i]); }
-    hipFree(b.blockErr); hipFree(b.blockTot); hipFree(b.blockOff); hipFree(b.estSumm); hipFree(b.blockL1); hipFree(b.blockAlive); hipFree(b.blockVal); hipFree(b.blockSpine); hipFree(b.chainLut);
     hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;
@@ -272,6 +297,8 @@ static vr_status sync_ctrl(BrickSet &b)
     if (b.hostCtrlValid) return VR_OK;
     HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
     HIPCHK(hipMemcpy(b.hostCtrl.data(), b.mid.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
+    b.lutZeroRun = 0;
+    if (b.chainLut && !b.foreign) HIPCHK(hipMemcpy(&b.lutZeroRun, b.chainLut + 256, sizeof(uint32_t), hipMemcpyDeviceToHost));
     b.hostCtrlValid = true;
     return VR_OK;
 }
@@ -295,6 +322,7 @@ vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
     info->max_error_before = c.maxErrBefore;
     info->max_error_after = c.maxErrAfter;
     info->mean_l1_after = (double)c.statL1 / (double)b.leafStride;
+    info->zero_run_rewrites = c.constBrick ? 0 : c.zeroRun + (int32_t)b.lutZeroRun;
     return VR_OK;
 }
 

@@ -62,6 +62,10 @@ struct Ctrl {
     int32_t emitOverflow;    // emit refused to write past the stream buffer (internal error)
     int32_t constBrick;      // every voxel of the brick has the same value: closed-form result (k_const_finish)
     int32_t constVal;
+    int32_t zeroRun;         // grown branches that ended on an evaluated "keep" code: the reference would rewrite that
+                             // run of zeros to 3s (R.cpp:662-669,686-688).  Provably never happens for tolerance >= 0
+                             // (the last distance is 1), so the emitters do not implement the rewrite; they count here
+                             // and the tests assert zero (the oracle counts its own firings the same way)
     uint8_t distanceMap[VR_MAX_DEPTH + 8];
 };
 

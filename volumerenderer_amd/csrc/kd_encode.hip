@@ -235,7 +235,7 @@ __global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *
 {
     Ctrl &c = ctrls[blockIdx.x];
     if (threadIdx.x) return;
-    c.constBrick = 0; c.constVal = 0;
+    c.constBrick = 0; c.constVal = 0; c.zeroRun = 0;
     if (rootMin) {
         const int mn = rootMin[(int64_t)blockIdx.x * mmStride], mx = rootMax[(int64_t)blockIdx.x * mmStride];
         c.constBrick = mn == mx ? 1 : 0;
@@ -1034,13 +1034,18 @@ __global__ void k_chain_lut(int tol, int nsteps, uint32_t *__restrict__ lut)
     const int m0 = threadIdx.x, t = 128;
     int rec = m0 <= 127 ? t - m0 : 0;
     uint32_t bits = 0, n = 0;
+    int lastKeep = 0;                 // the last evaluated branch node kept its parent's value (code 0)
     for (int i = 0; i < nsteps; ++i) {
         const int err = rec > t ? rec - t : t - rec;
-        if (err > tol) { const Enc e = encode_node(t, rec, 64 >> i); rec = e.recon; bits |= (uint32_t)e.code << (2 * n); ++n; }
+        if (err > tol) { const Enc e = encode_node(t, rec, 64 >> i); rec = e.recon; bits |= (uint32_t)e.code << (2 * n); ++n; lastKeep = e.code == 0; }
         else { bits |= 3u << (2 * n); ++n; break; }
     }
     const int fe = rec > t ? rec - t : t - rec;
     lut[m0] = (uint32_t)fe | (n << 8) | (bits << 16);     // byte 0: final error, byte 1: token count, bytes 2-3: tokens
+    // entries 0..127 are the ones a leaf can reach through the table (m0 <= min(t, 255 - t)); one that ends on a
+    // "keep" would need the reference's zero-run rewrite (R.cpp:662-669,686-688): counted, asserted zero by the tests
+    const int zr = __syncthreads_count(m0 <= 127 && lastKeep);
+    if (m0 == 0) lut[256] = (uint32_t)zr;
 }
 __device__ __forceinline__ uint32_t chain_mirror(uint32_t ch) { return ch ^ (((ch ^ (ch >> 1)) & 0x1555u) * 3u); }   // add <-> sub
 
@@ -1242,6 +1247,7 @@ struct Owned {
     int preDs;       // tokens owned by r that precede the depth-Ds node (index entry)
     int aliveAtDs;
     int finalErr;    // |recon - temp| of the leaf after branch growth (-1: leaf not visited)
+    int zeroRun;     // the branch ended on an evaluated "keep" at the last level (Ctrl::zeroRun)
 };
 
 __device__ inline Owned owned_tokens(const uint8_t *__restrict__ Cb, const uint8_t *__restrict__ CbR,
@@ -1252,7 +1258,7 @@ __device__ inline Owned owned_tokens(const uint8_t *__restrict__ Cb, const uint8
 {
     Owned o;
     o.spineBits = 0; o.leafBits = 0; o.spineBitsR = 0; o.leafBitsR = 0;
-    o.nSpine = 0; o.nLeaf = 0; o.preDs = 0; o.aliveAtDs = 0; o.finalErr = -1;
+    o.nSpine = 0; o.nLeaf = 0; o.preDs = 0; o.aliveAtDs = 0; o.finalErr = -1; o.zeroRun = 0;
     const int jmin = r ? D - (__ffs((int)r) - 1) : 0;
     bool alive = true;
     if (jmin > 0) alive = cget(Cb, ((int64_t)1 << (jmin - 1)) + (r >> (D - jmin + 1))) != 3;
@@ -1284,6 +1290,7 @@ __device__ inline Owned owned_tokens(const uint8_t *__restrict__ Cb, const uint8
                     depth++;
                     Enc e = encode_node(t, rec, dmap[depth]);
                     rec = e.recon;
+                    if (depth == maxDepth && e.code == 0) o.zeroRun = 1;
                     o.leafBits |= (uint32_t)e.code << (2 * o.nLeaf);
                     if (CbR) {                         // M.cpp: range stream re-encoded in lock-step
                         Enc er = encode_node(tR, recR, dmapR[depth]);
@@ -1472,7 +1479,7 @@ k_prune_emit12(PruneEmitArgs a)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {          // two halves of four sibling pairs: halves the transient registers
         uint32_t T2[4], m[4], sg[4], act[4];
-        uint32_t anyAct = 0;
+        uint32_t anyAct = 0, keepEnd = 0;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j = half * 4 + jj;
@@ -1520,12 +1527,16 @@ k_prune_emit12(PruneEmitArgs a)
                 const uint32_t take = go & pk_u((ax - mm) >> 15);
                 const uint32_t dir = pk_u(pk_s(0x00010001u) - pk_s(sg[jj]));                        // add = 1, sub = 2
                 Lb[j] |= ((take & dir) | term) << (2 * i + 2);
+                // an evaluated node that keeps leaves its error (> tol) unchanged, so the branch goes on unless this
+                // was the last level: only there can a branch end on a "keep" (zero-run rewrite, see Ctrl::zeroRun)
+                if (i == nsteps - 1) keepEnd |= go & ~take;
                 m[jj] = (take & pk_u(ax)) | (~take & m[jj]);
                 sg[jj] ^= take & pk_u(nx >> 15);
                 act[jj] = go;
                 anyAct |= go;
             }
         }
+        if (keepEnd) atomicAdd(&c.zeroRun, (int)((keepEnd & 1u) + ((keepEnd >> 16) & 1u)));
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) { mxA = __builtin_elementwise_max(mxA, pk_s(m[jj])); l1p += pk_s(m[jj]); }
     }
@@ -1791,8 +1802,9 @@ k_emit_write(EmitArgs a)
     const uint32_t r = blockIdx.x * EMIT_RANKS_PER_BLOCK + threadIdx.x;
     for (int i = threadIdx.x; i < EMIT_LDS_WORDS; i += blockDim.x) { W[i] = 0; WR[i] = 0; }
     Owned o;
-    o.nSpine = o.nLeaf = 0; o.finalErr = -1; o.aliveAtDs = 0; o.preDs = 0;
+    o.nSpine = o.nLeaf = 0; o.finalErr = -1; o.aliveAtDs = 0; o.preDs = 0; o.zeroRun = 0;
     if (r < n) o = owned_tokens(Cb, CbR, Tb, TbR, Rl, RlR, a.D, a.maxDepth, a.tol, c.distanceMap, dmapR, a.Ds, r);
+    if (o.zeroRun) atomicAdd(&c.zeroRun, 1);
     uint32_t w = o.nSpine + o.nLeaf, tot;
     uint32_t lo = block_excl_scan_u32(w, shw, tot); // also orders the LDS clear above
     const uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blockIdx.x];
@@ -1839,7 +1851,7 @@ k_emit_write(EmitArgs a)
 #define EMIT4_LDS_WORDS 640     // >= (1024*8 + 1023 + 28 + 15) / 16
 
 struct Str128 { unsigned long long lo, hi; int n; };
-struct Quad { Str128 s; int preDs, aliveAtDs; };
+struct Quad { Str128 s; int preDs, aliveAtDs, zeroRun; };
 
 // inner: codes of the block's internal nodes at depths D-10 .. D-3, heap-ordered (node (l, i) at (1<<l)+i)
 // lutS: k_chain_lut's table (LDS copy)
@@ -1861,7 +1873,7 @@ __device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const
                                    unsigned long long upSpine, int D, int maxDepth, int tol, int Ds, uint32_t r0)
 {
     Quad Q;
-    Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0;
+    Q.s.lo = Q.s.hi = 0; Q.s.n = 0; Q.preDs = 0; Q.aliveAtDs = 0; Q.zeroRun = 0;
     const uint32_t lr = r0 & 1023u;                                  // rank inside the block
     const int quadCode = (int)((in.quadB >> (((r0 >> 2) & 3u) * 2u)) & 3u);
     const uint32_t pk2 = (in.pairB >> (((r0 >> 1) & 3u) * 2u)) & 15u;                // mine: two of the four
@@ -1935,6 +1947,7 @@ __device__ inline Quad quad_tokens(const QuadIn &in, const uint8_t *inner, const
                                     ++depth;
                                     const Enc en = encode_node(t, rec, 64 >> (depth - D - 1));   // distanceMap[D+1..] = 64 .. 1
                                     rec = en.recon;
+                                    if (depth == maxDepth && en.code == 0) Q.zeroRun += 1;
                                     bits |= (uint32_t)en.code << (2 * nt);
                                     ++nt;
                                 } else { bits |= 3u << (2 * nt); ++nt; break; }
@@ -2046,6 +2059,7 @@ k_emit4(EmitArgs a)
         return;
     }
     const uint32_t phase = g0 & 15u;
+    if (Q.zeroRun) atomicAdd(&c.zeroRun, Q.zeroRun);
     // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
     // would be a bug; it must surface as a failed parity check, not as a memory fault)
     if (((unsigned long long)g0 + tot + 32ull) * 2ull > (unsigned long long)a.treeCap * 8ull) {

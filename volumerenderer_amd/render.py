@@ -75,8 +75,15 @@ def assemble_bricks(bricks, brick_dims, brick_ijk, grid, out=None, stream=None):
     g = (C.c_int64 * 3)(*[int(q) for q in grid])
     ijk = np.ascontiguousarray(brick_ijk, np.int64).reshape(-1, 3)
     nb = ijk.shape[0]
+    # the volume is the whole I x J x K grid (VolumeReader.h:184-198 writes at grid coordinates); cells with no
+    # brick stay zero.  (The reference sizes it by numBricks, VolumeReader.h:163-168, and overruns for sparse lists.)
+    vol_bytes = g[0] * g[1] * g[2] * bd[0] * bd[1] * bd[2]
+    if b.numel() < nb * bd[0] * bd[1] * bd[2]:
+        raise ValueError("assemble_bricks: %d bricks need %d bytes, got %d" % (nb, nb * bd[0] * bd[1] * bd[2], b.numel()))
     if out is None:
-        out = torch.zeros(nb * bd[0] * bd[1] * bd[2], dtype=torch.uint8, device="cuda")
+        out = torch.zeros(vol_bytes, dtype=torch.uint8, device="cuda")
+    elif out.numel() < vol_bytes:
+        raise ValueError("assemble_bricks: the volume needs I*J*K*X*Y*Z = %d bytes, out has %d" % (vol_bytes, out.numel()))
     check(_lib.lib().vr_assemble_bricks(C.c_void_p(b.data_ptr()), nb, bd, ijk.ctypes.data_as(C.POINTER(C.c_int64)), g,
                                         C.c_void_p(out.data_ptr()), _stream_ptr(stream)), "vr_assemble_bricks")
     return out
@@ -88,8 +95,13 @@ def disassemble_bricks(volume, brick_dims, brick_ijk, grid, out=None, stream=Non
     g = (C.c_int64 * 3)(*[int(q) for q in grid])
     ijk = np.ascontiguousarray(brick_ijk, np.int64).reshape(-1, 3)
     nb = ijk.shape[0]
+    vol_bytes = g[0] * g[1] * g[2] * bd[0] * bd[1] * bd[2]
+    if v.numel() < vol_bytes:
+        raise ValueError("disassemble_bricks: the volume must hold I*J*K*X*Y*Z = %d bytes, got %d" % (vol_bytes, v.numel()))
     if out is None:
         out = torch.empty(nb * bd[0] * bd[1] * bd[2], dtype=torch.uint8, device="cuda")
+    elif out.numel() < nb * bd[0] * bd[1] * bd[2]:
+        raise ValueError("disassemble_bricks: out is too small")
     check(_lib.lib().vr_disassemble_bricks(C.c_void_p(v.data_ptr()), nb, bd, ijk.ctypes.data_as(C.POINTER(C.c_int64)), g,
                                            C.c_void_p(out.data_ptr()), _stream_ptr(stream)), "vr_disassemble_bricks")
     return out
