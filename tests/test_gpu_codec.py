@@ -457,13 +457,20 @@ def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shap
         bs.build(vol.copy())
         assert np.array_equal(bs.tree(0), ref.tree)
         D = ref.origTreeDepth
-        cuts = [None, D, D - 1, D - 5, D - 6, D - 7, 3, int(rng.integers(1, ref.maxTreeDepth + 1))]
+        M = ref.maxTreeDepth
+        cuts = [None, D, D - 1, D - 2, D - 3, D - 4, D - 5, D - 6, D - 7, 3, D + 1, D + 4, M - 1,
+                int(rng.integers(1, ref.maxTreeDepth + 1))]
         for cut in cuts:
             want = ref.levelCut() if cut is None else ref.levelCutProgressive(cut)
+            # default: k_decode_quad for cuts >= D-3 (one table lookup per voxel leaf), k_decode_fine above
+            quad = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
+            monkeypatch.setenv("VRHIP_DECODE_FINE_V1", "1")
             fine = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
+            monkeypatch.delenv("VRHIP_DECODE_FINE_V1")
             monkeypatch.setenv("VRHIP_DECODE_WALK", "1")
             walk = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
             monkeypatch.delenv("VRHIP_DECODE_WALK")
+            assert np.array_equal(quad, want), (case, tol, ep, cut)
             assert np.array_equal(fine, want), (case, tol, ep, cut)
             assert np.array_equal(walk, want), (case, tol, ep, cut)
         # the same bytes installed as a foreign stream (what open() does): the per-4-leaf counts then come from
@@ -471,7 +478,8 @@ def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shap
         fs = vr.BrickSet(1, (x, y, z), tol, ep)
         fs.set_tree(0, ref.tree, ref.numActiveNodes, ref.distanceMap)
         assert np.array_equal(fs.decode().cpu().numpy().reshape(shape), ref.levelCut()), (case, tol, ep, "foreign")
-        assert np.array_equal(fs.decode(cut_depth=D - 2).cpu().numpy().reshape(shape), ref.levelCutProgressive(D - 2))
+        for cut in (D - 2, D - 3, D - 4, D + 2):
+            assert np.array_equal(fs.decode(cut_depth=cut).cpu().numpy().reshape(shape), ref.levelCutProgressive(cut)), cut
 
 
 def test_hashed_kdtree_interface(vr, oracle):

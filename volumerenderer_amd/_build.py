@@ -11,6 +11,8 @@ HEADERS = ["kd_common.h", "brickset.h", os.path.join("..", "..", "include", "vrh
 # exactly like the reference's scalar code (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
+# experiments: extra -D switches for tuning runs (part of the staleness hash, so a change rebuilds)
+FLAGS += os.environ.get("VRHIP_EXTRA_HIPCC_FLAGS", "").split()
 
 
 STAMP = LIB + ".srchash"

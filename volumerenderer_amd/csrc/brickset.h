@@ -45,6 +45,10 @@ struct BrickSet {
     uint8_t *fineIdx = nullptr;   // B * nIdx * 16  tokens owned by each 4-leaf subtree of a depth-Ds node (fused encoder only)
     std::vector<uint8_t> fineHas; // per brick: fineIdx describes its current stream (all set -> k_decode_fine)
     uint32_t *decTables = nullptr; // B * FD_TABLE_WORDS: k_decode_fine's tables of every brick for the current cut
+    uint8_t *idxVal3 = nullptr;   // B * nIdx * 8   decoded scalar of every depth-(D-3) node (k_decode_quad; with fineIdx)
+    uint32_t *chainTab = nullptr; // 16384 entries: k_decode_quad's grown-branch table for `chainTabLevels` refining levels
+    int chainTabLevels = -1;
+    void *chainTabStream = nullptr;
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
     bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream
@@ -70,7 +74,7 @@ int cut_values_from_stream(BrickSet *bs, const uint8_t *treeHost, int64_t numAct
                            std::vector<uint8_t> &vals);
 int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *treeHost, int64_t numActive,
                             const uint8_t *dmapHost, std::vector<uint32_t> &offs, std::vector<uint8_t> &vals,
-                            std::vector<uint8_t> &fine);
+                            std::vector<uint8_t> &fine, std::vector<uint8_t> &val3);
 void make_geom(Geom &g, const int64_t dims[3]);
 void make_lut(const Geom &g, int K, std::vector<uint32_t> &lut);
 

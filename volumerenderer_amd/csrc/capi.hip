@@ -187,7 +187,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_encoder_buffers(b);
     free_stream2(b.mid);
     free_stream2(b.rng);
-    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread);
+    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.idxVal3); hipFree(b.chainTab); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;
     return VR_OK;
@@ -459,8 +459,12 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     const int64_t need = (num_active + 3) / 4;
     if (tree_bytes < need || need > b.treeCap) return VR_ERR_FORMAT;
     std::vector<uint32_t> offs;
-    std::vector<uint8_t> vals, fine;
-    if (build_index_from_stream(&b, brick, tree, num_active, dmap, offs, vals, fine) != 0) return VR_ERR_FORMAT;
+    std::vector<uint8_t> vals, fine, val3;
+    if (build_index_from_stream(&b, brick, tree, num_active, dmap, offs, vals, fine, val3) != 0) return VR_ERR_FORMAT;
+    // the fine decoders take the grown-branch distances as the constants the reference writes (R.cpp:94-97); a
+    // file that says otherwise is decoded by the walking kernel, which reads them from the map
+    for (int i = 0; i < VR_CHAIN_LEVELS; ++i)
+        if (dmap[b.D + 1 + i] != (uint8_t)(64 >> i)) { fine.clear(); val3.clear(); }
     if (!b.built) { // first foreign tree: other bricks stay empty until set
         b.fineHas.assign((size_t)b.B, 1);   // (their index is all "pruned": no counts are read)
         HIPCHK(hipMemset(b.mid.ctrl, 0, (size_t)b.B * sizeof(Ctrl)));
@@ -489,6 +493,8 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     if (!fine.empty()) {
         if (!b.fineIdx) HIPCHK(hipMalloc(&b.fineIdx, (size_t)b.B * b.nIdx * 16));
         HIPCHK(hipMemcpy(b.fineIdx + (size_t)brick * b.nIdx * 16, fine.data(), fine.size(), hipMemcpyHostToDevice));
+        if (!b.idxVal3) HIPCHK(hipMalloc(&b.idxVal3, (size_t)b.B * b.nIdx * 8));
+        HIPCHK(hipMemcpy(b.idxVal3 + (size_t)brick * b.nIdx * 8, val3.data(), val3.size(), hipMemcpyHostToDevice));
         b.fineHas[(size_t)brick] = 1;
     }
     if ((int)b.hostTree.size() != b.B) b.hostTree.assign((size_t)b.B, std::vector<uint8_t>());

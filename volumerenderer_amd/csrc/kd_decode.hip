@@ -158,7 +158,8 @@ struct TileArgs {
     const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
     const uint32_t *spread;     // BrickSet::spread (coordinate -> Morton rank bits)
     const uint8_t *fine;        // BrickSet::fineIdx (k_decode_fine only)
-    const uint32_t *tables;     // BrickSet::decTables (k_decode_fine only)
+    const uint32_t *tables;     // BrickSet::decTables (k_decode_fine) / BrickSet::chainTab (k_decode_quad)
+    const uint8_t *val3;        // BrickSet::idxVal3 (k_decode_quad only)
 };
 
 #define DEC_WAVES 4
@@ -240,6 +241,60 @@ __device__ __forceinline__ void tile_gather(const TileArgs &a, const uint32_t *t
         const int64_t gy = (int64_t)ty * 8 + y, gz = (int64_t)tz * 4 + z;
         *(uint4 *)(O + (int64_t)a.g.X * (gy + (int64_t)a.g.Y * gz)) = make_uint4(o[0], o[1], o[2], o[3]);
     }
+}
+
+
+// the same gather with wide LDS reads (k_decode_quad).  A 16-byte row piece = the voxels x = 16c .. 16c+15 of one (y, z)
+// = the same leaf positions of four neighbouring blocks 4c .. 4c+3, whose tile words are consecutive: one ds_read_b128
+// per (dx bit 1 [, dx bit 0]) brings them all, v_perm picks the bytes.  y = lane >> 3 and z = the store's index.
+__device__ __forceinline__ void tile_gather_wide(const TileArgs &a, const uint32_t *tile, int stride, int brick,
+                                                 int tx, int ty, int tz, int lane)
+{
+    const int jx = a.jx, jy = a.jy, jz = a.jz;
+    const int c = lane & 7, y = lane >> 3, dy = y & 3;
+    uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16 +
+                 (int64_t)a.g.X * ((int64_t)ty * 8 + y + (int64_t)a.g.Y * ((int64_t)tz * 4));
+    const int64_t zs = (int64_t)a.g.X * a.g.Y;
+    const uint32_t rby = ((uint32_t)(dy & 1) << jy) | ((uint32_t)(dy >> 1) << (3 + jy));
+    const uint32_t *col = tile + 4 * c + 32 * (y >> 2);              // my four blocks' column of the tile
+    if (jx < 2) {                                                     // dx bit 0 lives in the byte index
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            const uint32_t rb = rby | ((uint32_t)(z & 1) << jz) | ((uint32_t)(z >> 1) << (3 + jz));
+            const uint32_t b0 = rb & 3u, b1 = b0 | (1u << jx);
+            const uint32_t sel = b0 | (b1 << 8) | ((4u + b0) << 16) | ((4u + b1) << 24);
+            const uint32_t g0 = rb >> 2, g1 = g0 | (2u << jx);
+            const uint4 A = *(const uint4 *)(col + g0 * stride), B = *(const uint4 *)(col + g1 * stride);
+            *(uint4 *)(O + zs * z) = make_uint4(__builtin_amdgcn_perm(B.x, A.x, sel), __builtin_amdgcn_perm(B.y, A.y, sel),
+                                                __builtin_amdgcn_perm(B.z, A.z, sel), __builtin_amdgcn_perm(B.w, A.w, sel));
+        }
+    } else {                                                          // jx == 2: dx bit 0 is bit 0 of the word's row
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            const uint32_t rb = rby | ((uint32_t)(z & 1) << jz) | ((uint32_t)(z >> 1) << (3 + jz));
+            const uint32_t b = rb & 3u, sel = b | ((4u + b) << 8) | 0x0c0c0000u;
+            const uint32_t g0 = rb >> 2;
+            const uint4 A = *(const uint4 *)(col + g0 * stride), B = *(const uint4 *)(col + (g0 | 1u) * stride),
+                        C = *(const uint4 *)(col + (g0 | 8u) * stride), E = *(const uint4 *)(col + (g0 | 9u) * stride);
+            const auto mk = [sel](uint32_t w00, uint32_t w01, uint32_t w10, uint32_t w11) {
+                return __builtin_amdgcn_perm(__builtin_amdgcn_perm(w11, w10, sel), __builtin_amdgcn_perm(w01, w00, sel), 0x05040100u);
+            };
+            *(uint4 *)(O + zs * z) = make_uint4(mk(A.x, B.x, C.x, E.x), mk(A.y, B.y, C.y, E.y), mk(A.z, B.z, C.z, E.z), mk(A.w, B.w, C.w, E.w));
+        }
+    }
+}
+
+// a tile whose 64 blocks all lie under pruned nodes: row 0 of the tile holds one replicated value per block, a row
+// piece is four consecutive words of it, the same for the tile's four z
+__device__ __forceinline__ void tile_fill_dead(const TileArgs &a, const uint32_t *tile, int brick, int tx, int ty, int tz, int lane)
+{
+    const int c = lane & 7, y = lane >> 3;
+    uint8_t *O = a.out + (int64_t)brick * a.g.voxels + (int64_t)tx * 128 + c * 16 +
+                 (int64_t)a.g.X * ((int64_t)ty * 8 + y + (int64_t)a.g.Y * ((int64_t)tz * 4));
+    const int64_t zs = (int64_t)a.g.X * a.g.Y;
+    const uint4 v = *(const uint4 *)(tile + 4 * c + 32 * (y >> 2));
+#pragma unroll
+    for (int z = 0; z < 4; ++z) *(uint4 *)(O + zs * z) = v;
 }
 
 __global__ void __launch_bounds__(64 * DEC_WAVES)
@@ -661,6 +716,253 @@ k_decode_fine(TileArgs a)
     tile_gather(a, tile, FD_TS, liveMask == 0ull ? 0 : 1, brick, tx, ty, tz, lane);
 }
 
+
+// ---- quad decode (the roofline kernel) -----------------------------------------------------------
+// Same tile, same side-car counts as k_decode_fine, one lane per four voxels, but nothing on the step's critical
+// path waits for LDS and a voxel leaf is ONE table lookup:
+//   * the scalars of the depth-(D-3) nodes come from a third side-car (8 bytes per depth-Ds node, written by
+//     k_concat12 / the host parse), so the per-tile pass that decoded the 15 upper nodes of every block -- and
+//     re-read their tokens -- is gone: a tile starts by parking (scalar, count) per 4-leaf subtree;
+//   * a lane's tokens (at most 4 + 3 + 4 * 8 = 39) sit in three 32-bit windows cut from its four stream words with
+//     v_alignbit; where a leaf ends follows from the positions of the '3' tokens in its window
+//     (x & x >> 1 & 0x5555, v_ffbl): no table, no LDS round trip between a leaf and its successor;
+//   * the grown branch (R.cpp:655-704 as levelCut sees it, R.cpp:783-787) is one lookup in a 16384-entry table keyed
+//     by its seven tokens: the composed clamp-add v -> min(max(v + A, LO), HI).  Branch distances are 64..1 for every
+//     brick (R.cpp:94-97), so ONE table serves the launch (64 KiB of LDS per 16-wave workgroup); tokens behind the
+//     first '3' are forced to '3' before the lookup, so a leaf's key never depends on its successor's tokens;
+//   * a pruned node is a token that reads as '3' (also forced where an ancestor is pruned): its subtree's voxels take
+//     its parent's scalar through selects, never through exec-mask branches.
+#define QD_WAVES 16
+#ifndef QD_TPW
+#define QD_TPW 4            // tiles per wave: amortises the table copy
+#endif
+#define QD_TS 68            // tile row stride in words (as FD_TS)
+#ifndef QD_PF
+#define QD_PF 4             // steps the stream-word requests run ahead
+#endif
+#define QD_CHAIN_ENTRIES 16384
+
+// entry: byte 0 = A (int8), byte 2 = LO, byte 3 = HI; `levels` = branch levels at or above the cut (7: levelCut at
+// full depth; fewer: progressive cut inside the branch, deeper levels refine nothing)
+__global__ void __launch_bounds__(256)
+k_chain_table(int levels, uint32_t *__restrict__ out)
+{
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    int A = 0, LO = 0, HI = 255;
+    for (int q = 0; q < VR_CHAIN_LEVELS; ++q) {
+        const int tok = (int)((idx >> (2 * q)) & 3u);
+        if (tok == 3) break;
+        const int dist = q < levels ? (64 >> q) : 0;
+        const int dl = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+        A += dl;
+        LO += dl; LO = LO < 0 ? 0 : (LO > 255 ? 255 : LO);
+        HI += dl; HI = HI < 0 ? 0 : (HI > 255 ? 255 : HI);
+    }
+    out[idx] = (uint32_t)(A & 255) | ((uint32_t)LO << 16) | ((uint32_t)HI << 24);
+}
+
+__device__ __forceinline__ uint32_t ffbl_u32(uint32_t x)
+{   // index of the lowest set bit, 0xFFFFFFFF for 0
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t ones_from(uint32_t f, uint32_t x)
+{   // x | (~0 << (f & 31)) in one instruction
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, -1, %1, %2" : "=v"(r) : "v"(f), "v"(x));
+    return r;
+}
+
+struct QuadDist { int d4, d5, d6; };     // distances of depths D-2, D-1, D (0 below a progressive cut)
+
+// one voxel leaf: yl = the 16 bits that start at its code.  Returns the voxel; e = bits before its last token
+// (the leaf takes e + 2 bits: code + branch tokens up to and including the terminator, at most 8 tokens)
+__device__ __forceinline__ int qd_leaf(uint32_t yl, int V5, int d6, const uint32_t *chainS, uint32_t &e)
+{
+    const uint32_t T = yl & (yl >> 1) & 0x5555u;            // bit 2i <=> token i is '3' (i = 0: the code, a pruned leaf)
+    const uint32_t f = ffbl_u32(T);
+    e = min(f, 14u);
+    const int sc = __builtin_amdgcn_sbfe((int)yl, 0, 2);    // code 1 -> +1, 2 -> -2, 3 -> -1
+    const int Vc = med3i(mad24i((sc + 1) >> 1, d6, V5), 0, 255);           // R.cpp:783-787
+    const uint32_t ym = ones_from(f, yl);                   // the tokens from the first '3' on read as '3'
+    const uint32_t ent = *(const uint32_t *)((const char *)chainS + (ym & 0xFFFCu));   // branch tokens = bits 2..15
+    int v = Vc + (int)(int8_t)(ent & 255u);
+    v = min(max(v, (int)((ent >> 16) & 255u)), (int)(ent >> 24));
+    return v;
+}
+
+// a depth-(D-1) node and its two leaves: y = the 32 bits that start at the node's token, yh the 32 after them.
+// Returns the two voxels (bytes 0, 1); used = bits the pair takes.
+__device__ __forceinline__ uint32_t qd_pair(uint32_t y, uint32_t yh, bool dead, int Vp, const QuadDist &qd,
+                                            const uint32_t *chainS, uint32_t &used)
+{
+    int s5 = __builtin_amdgcn_sbfe((int)y, 0, 2);
+    s5 = dead ? -1 : s5;
+    const int V5 = med3i(mad24i((s5 + 1) >> 1, qd.d5, Vp), 0, 255);
+    const bool pr = s5 == -1;                               // pruned (or under a pruned node): both voxels = Vp
+    uint32_t e1, e2;
+    int v1 = qd_leaf(y >> 2, V5, qd.d6, chainS, e1);
+    int v2 = qd_leaf(__builtin_amdgcn_alignbit(yh, y, e1 + 4u), V5, qd.d6, chainS, e2);
+    v1 = pr ? Vp : v1;
+    v2 = pr ? Vp : v2;
+    used = pr ? 2u : e1 + e2 + 6u;
+    return (uint32_t)v1 | ((uint32_t)v2 << 8);
+}
+
+__global__ void __launch_bounds__(64 * QD_WAVES)
+k_decode_quad(TileArgs a)
+{
+    // one struct: the table sits at LDS address 0, so a lookup's address is the masked key itself
+    struct Shared {
+        uint32_t chain[QD_CHAIN_ENTRIES];
+        uint32_t tile[QD_WAVES][16 * QD_TS];    // [leaf / 4][block of the tile]
+        uint32_t off[QD_WAVES][64];             // per block of the tile: token offset of its root
+        int next;                               // next tile of the workgroup nobody has taken yet
+    };
+    __shared__ __attribute__((aligned(16))) Shared sm;
+    uint32_t *chainS = sm.chain;
+    uint32_t (*offS)[64] = sm.off;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int brick = blockIdx.y;
+    const int ntiles = a.tilesX * a.tilesY * a.tilesZ;
+    const int tile0 = blockIdx.x * (QD_WAVES * QD_TPW);               // the workgroup's tiles: tile0 .. tile0 + 16 * QD_TPW - 1
+    uint32_t *tile = sm.tile[wave];
+    // ---- does anybody here need the table?  (index offsets of all the workgroup's tiles, QD_TPW per thread)
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < QD_TPW; ++k) {
+        const int tileId = tile0 + wave * QD_TPW + k;
+        if (tileId < ntiles) {
+            const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
+            const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
+            const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
+            any = any || a.idxOff[(int64_t)brick * a.nIdx + s] != VR_IDX_DEAD;
+        }
+    }
+    if (threadIdx.x == 0) sm.next = 0;
+    if (__syncthreads_or(any ? 1 : 0)) {
+        const uint4 *src = (const uint4 *)a.tables;
+        uint4 *dst = (uint4 *)chainS;
+#pragma unroll
+        for (int i = 0; i < QD_CHAIN_ENTRIES / 4 / (64 * QD_WAVES); ++i) dst[i * 64 * QD_WAVES + threadIdx.x] = src[i * 64 * QD_WAVES + threadIdx.x];
+        __syncthreads();
+    }
+    QuadDist qd;
+    {
+        const uint8_t *dmap = a.ctrls[brick].distanceMap;
+        qd.d4 = a.D - 2 <= a.cut ? dmap[a.D - 2] : 0;
+        qd.d5 = a.D - 1 <= a.cut ? dmap[a.D - 1] : 0;
+        qd.d6 = a.D <= a.cut ? dmap[a.D] : 0;
+    }
+    const int g = lane & 15;
+    const uint32_t ownN = g == 0 ? 4u : (uint32_t)(__ffs(g) - 1);     // ancestors (depth >= Ds) whose tokens head my run
+    const uint32_t p0 = 2u * ownN, p1 = p0 + 2u;                       // bit of my root's token / of my first pair's
+    const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
+    // ---- the waves take the workgroup's tiles from a counter: tiles in pruned regions cost a fraction of a detailed
+    // one, and with the table only one workgroup fits a CU, so a fixed split would leave SIMDs idle behind the slowest wave
+    while (true) {
+        int kq = 0;
+        if (lane == 0) kq = atomicAdd(&sm.next, 1);
+        kq = __builtin_amdgcn_readfirstlane(kq);
+        const int tileId = tile0 + kq;
+        if (kq >= QD_WAVES * QD_TPW || tileId >= ntiles) break;       // wave-uniform
+        const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
+        const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
+        const uint32_t sB = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
+        const int64_t io = (int64_t)brick * a.nIdx + sB;
+        const uint32_t off = a.idxOff[io];
+        const uint32_t val0 = a.idxVal[io];
+        const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
+        if (liveMask == 0ull) tile[lane] = val0 * 0x01010101u;          // as in k_decode_tile: one value per block
+        else {
+            // ---- park (scalar of its depth-(D-3) parent, tokens it owns) for each 4-leaf subtree of my block; a block
+            // under a pruned node parks its final words
+            const bool deadB = off == VR_IDX_DEAD;
+            uint4 cv = make_uint4(0, 0, 0, 0);
+            uint2 sv = make_uint2(0, 0);
+            if (!deadB) {
+                cv = *(const uint4 *)(a.fine + io * 16);
+                sv = *(const uint2 *)(a.val3 + io * 8);
+            }
+            offS[wave][lane] = off;
+            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, sw[2] = {sv.x, sv.y};
+            const uint32_t rep = val0 * 0x01010101u;
+#pragma unroll
+            for (int gg = 0; gg < 16; ++gg) {
+                const uint32_t w = __builtin_amdgcn_perm(cw[gg >> 2], sw[gg >> 3],
+                                                         0x0c0c0000u | ((4u + (uint32_t)(gg & 3)) << 8) | (uint32_t)((gg >> 1) & 3));
+                tile[gg * QD_TS + lane] = deadB ? rep : w;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // ---- 16 steps of 4 blocks x 16 lanes.  The stream words of a step are requested QD_PF steps ahead: a step is
+            // ~130 instructions, far shorter than a trip to memory, and with 64 KiB of table a CU holds 16 waves
+            uint32_t qw[QD_PF][4], qb[QD_PF], qV[QD_PF];
+            bool qLive[QD_PF];
+#pragma unroll
+            for (int i = 0; i < QD_PF; ++i) { qw[i][0] = qw[i][1] = qw[i][2] = qw[i][3] = 0; qb[i] = 0; qV[i] = 0; qLive[i] = false; }
+            const auto request = [&](int it, int slot) {
+                if ((((uint32_t)(liveMask >> (4 * it))) & 15u) == 0u) return;       // wave-uniform
+                const int S = 4 * it + (lane >> 4);
+                const uint32_t so = offS[wave][S];
+                const uint32_t tw = tile[g * QD_TS + S];
+                const bool deadRow = so == VR_IDX_DEAD;
+                const uint32_t c = deadRow ? 0u : ((tw >> 8) & 255u);
+                qV[slot] = tw & 255u;
+                uint32_t inc = c;                                   // prefix sum within the row of 16 lanes
+                inc += dpp_u32<0x111, 0xf>(0, inc);
+                inc += dpp_u32<0x112, 0xf>(0, inc);
+                inc += dpp_u32<0x114, 0xf>(0, inc);
+                inc += dpp_u32<0x118, 0xf>(0, inc);
+                const uint32_t tokpos = (deadRow ? 0u : so) + inc - c;
+                const uint32_t *Wp = W + (tokpos >> 4);
+                qb[slot] = (tokpos & 15u) * 2u;
+                // my root exists <=> I own more tokens than the ancestors heading my run (a pruned ancestor ends the run)
+                qLive[slot] = c > ownN;
+                qw[slot][0] = Wp[0]; qw[slot][1] = Wp[1]; qw[slot][2] = Wp[2]; qw[slot][3] = Wp[3];
+            };
+#pragma unroll
+            for (int i = 0; i < QD_PF; ++i) request(i, i);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const bool liveStep = (((uint32_t)(liveMask >> (4 * it))) & 15u) != 0u;   // wave-uniform
+                const int slot = it % QD_PF;
+                const uint32_t w0 = qw[slot][0], w1 = qw[slot][1], w2 = qw[slot][2], w3 = qw[slot][3], b = qb[slot];
+                const int V3 = (int)qV[slot];
+                const bool live = qLive[slot];
+                if (it + QD_PF < 16) request(it + QD_PF, slot);
+                if (liveStep) {
+                    const int S = 4 * it + (lane >> 4);
+                    // my tokens: bits [0, 96) from my first token on
+                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
+                                   hh = __builtin_amdgcn_alignbit(w3, w2, b);
+                    // my depth-(D-2) root (behind the ancestors' tokens)
+                    int s4 = __builtin_amdgcn_sbfe((int)lo, p0, 2);
+                    s4 = live ? s4 : -1;
+                    const int V4 = med3i(mad24i((s4 + 1) >> 1, qd.d4, V3), 0, 255);
+                    const bool dead = s4 == -1;
+                    uint32_t used1, used2;
+                    const uint32_t b01 = qd_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead, V4,
+                                                 qd, chainS, used1);
+                    const uint32_t p2 = p1 + used1;                   // <= 10 + 34
+                    const bool q = p2 >= 32u;
+                    const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
+                    const uint32_t b23 = qd_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead, V4,
+                                                 qd, chainS, used2);
+                    tile[g * QD_TS + S] = b01 | (b23 << 16);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (liveMask == 0ull) tile_fill_dead(a, tile, brick, tx, ty, tz, lane);
+        else tile_gather_wide(a, tile, QD_TS, brick, tx, ty, tz, lane);
+        __builtin_amdgcn_s_waitcnt(0xC07F);           // the next tile parks into the words the gather has just read
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 static bool tile_geometry(const BrickSet *bs, TileArgs &a)
 {
     const Geom &g = bs->g;
@@ -721,8 +1023,24 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         t.cut = cut; t.idxValCut = cutVals; t.spread = bs->spread;
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
         t.fine = bs->fineIdx;
+        t.val3 = bs->idxVal3;
         bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !rangeStream && !getenv("VRHIP_DECODE_WALK");
         for (int i = 0; useFine && i < bs->B; ++i) useFine = bs->fineHas[(size_t)i] != 0;
+        // k_decode_quad: cuts at or below depth D-3 (the third side-car holds the depth-(D-3) scalars at full
+        // precision); shallower progressive cuts keep k_decode_fine, which decodes the upper nodes itself
+        const bool useQuad = useFine && bs->idxVal3 && cut >= bs->D - 3 && !getenv("VRHIP_DECODE_FINE_V1");
+        if (useQuad) {
+            const int levels = cut - bs->D < 0 ? 0 : (cut - bs->D > VR_CHAIN_LEVELS ? VR_CHAIN_LEVELS : cut - bs->D);
+            if (!bs->chainTab && hipMalloc(&bs->chainTab, (size_t)QD_CHAIN_ENTRIES * 4) != hipSuccess) return -3;
+            if (bs->chainTabLevels != levels || bs->chainTabStream != (void *)st) {   // stream order keeps its readers safe
+                hipLaunchKernelGGL(k_chain_table, dim3(QD_CHAIN_ENTRIES / 256), dim3(256), 0, st, levels, bs->chainTab);
+                bs->chainTabLevels = levels;
+                bs->chainTabStream = (void *)st;
+            }
+            t.tables = bs->chainTab;
+            const int per = QD_WAVES * QD_TPW;
+            hipLaunchKernelGGL(k_decode_quad, dim3((unsigned)((ntiles + per - 1) / per), bs->B), dim3(64 * QD_WAVES), 0, st, t);
+        } else {
         if (useFine && !bs->decTables && hipMalloc(&bs->decTables, (size_t)bs->B * FD_TABLE_WORDS * 4) != hipSuccess) return -3;
         t.tables = bs->decTables;
         if (useFine)
@@ -733,6 +1051,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         else
             hipLaunchKernelGGL(k_decode_tile, dim3((unsigned)((ntiles + DEC_WAVES - 1) / DEC_WAVES), bs->B),
                                dim3(64 * DEC_WAVES), 0, st, t);
+        }
     } else {
         DecodeArgs a;
         a.tree = sm.tree; a.treeCap = bs->treeCap;
@@ -790,7 +1109,8 @@ int cut_values_from_stream(BrickSet *bs, const uint8_t *tree, int64_t numActive,
 // Serial pass over a foreign stream (host): the side-car index from the bytes alone.
 // Also validates the grammar.  Returns 0 or a negative code.
 int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *tree, int64_t numActive, const uint8_t *dmap,
-                            std::vector<uint32_t> &offs, std::vector<uint8_t> &vals, std::vector<uint8_t> &fine)
+                            std::vector<uint32_t> &offs, std::vector<uint8_t> &vals, std::vector<uint8_t> &fine,
+                            std::vector<uint8_t> &val3)
 {
     const int D = bs->D, Ds = bs->Ds;
     offs.assign((size_t)bs->nIdx, VR_IDX_DEAD);
@@ -799,6 +1119,7 @@ int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *tree, int64_
     // A token at depth >= Ds belongs to the 4-leaf subtree that holds its node's first leaf.
     const bool wantFine = bs->K == 6 && D >= 6;
     fine.assign(wantFine ? (size_t)bs->nIdx * 16 : 0, 0);
+    val3.assign(wantFine ? (size_t)bs->nIdx * 8 : 0, 0);      // decoded scalar of every depth-(D-3) node (k_decode_quad)
     auto own = [&](uint32_t path, int j) {
         if (!wantFine || j < Ds) return;
         const uint32_t first = path << (D - j);     // first leaf (rank) below the node
@@ -816,12 +1137,17 @@ int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *tree, int64_
         int val = j == 0 ? dmap[0] : apply_code(v[j - 1], tok, dmap[j]);
         v[j] = val;
         if (j == Ds) { offs[path] = (uint32_t)here; vals[path] = (uint8_t)val; }
+        if (wantFine && j == D - 3) val3[path] = (uint8_t)val;
         own(path, j);
         bool terminal = false;
         if (tok == 3) {
             if (j < Ds) {
                 uint32_t lo = path << (Ds - j), hi = (path + 1) << (Ds - j);
                 for (uint32_t q = lo; q < hi; ++q) { offs[q] = VR_IDX_DEAD; vals[q] = (uint8_t)val; }
+            }
+            if (wantFine && j < D - 3) {
+                uint32_t lo = path << (D - 3 - j), hi = (path + 1) << (D - 3 - j);
+                for (uint32_t q = lo; q < hi; ++q) val3[q] = (uint8_t)val;
             }
             terminal = true;
         } else if (j == D) {

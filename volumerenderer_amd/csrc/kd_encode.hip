@@ -1326,6 +1326,7 @@ struct EmitArgs {
     int64_t treeCap;
     uint32_t *idxOff;
     uint8_t *idxVal;
+    uint8_t *idxVal3;              // k_concat12: decoded scalars of the depth-(D-3) nodes (k_decode_quad)
     int64_t nIdx;
     const uint32_t *chainLut;
 };
@@ -2136,6 +2137,12 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
         csh[q] = (int)(ni & 3) * 2;
         dist[q] = c.distanceMap[j];
     }
+    // the three levels below my node (2 + 4 + 8 codes: the level loop's own, pruning only ever turns a 0 into a 3 and
+    // neither moves a scalar) for the depth-(D-3) scalars k_decode_quad starts from
+    const int64_t n5 = ((int64_t)1 << (D - 5)) + 2 * (int64_t)s, n4 = ((int64_t)1 << (D - 4)) + 4 * (int64_t)s,
+                  n3 = ((int64_t)1 << (D - 3)) + 8 * (int64_t)s;
+    const uint32_t c5 = (uint32_t)Cb[n5 >> 2] >> ((int)(n5 & 3) * 2), c4 = Cb[n4 >> 2], c3 = *(const uint16_t *)(Cb + (n3 >> 2));
+    const int dl5 = c.distanceMap[D - 5], dl4 = c.distanceMap[D - 4], dl3 = c.distanceMap[D - 3];
     const int nsp = (int)(upSpine >> 56);
     const unsigned long long spine = upSpine & 0x00FFFFFFFFFFFFFFull;
     {
@@ -2147,6 +2154,15 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
         }
         a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? g0 + (uint32_t)nsp + local : VR_IDX_DEAD;
         a.idxVal[io] = (uint8_t)val;
+        uint32_t lo3 = 0, hi3 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int v = apply_code(val, (int)((c5 >> (2 * (i >> 2))) & 3u), dl5);
+            v = apply_code(v, (int)((c4 >> (2 * (i >> 1))) & 3u), dl4);
+            v = apply_code(v, (int)((c3 >> (2 * i)) & 3u), dl3);
+            if (i < 4) lo3 |= (uint32_t)v << (8 * i); else hi3 |= (uint32_t)v << (8 * (i - 4));
+        }
+        *(uint2 *)(a.idxVal3 + io * 8) = make_uint2(lo3, hi3);
     }
     if (!(bflags & 1) || tot == 0) return;
     // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
@@ -2385,6 +2401,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.rb = rb; pa.subTok = bs->blockOff; pa.nEmitBlk = bs->nEmitBlk; pa.blockL1 = bs->blockL1;
         pa.chainLut = bs->chainLut; pa.idxOff = bs->idxOff; pa.nIdx = bs->nIdx;
         if (!bs->fineIdx && hipMalloc(&bs->fineIdx, (size_t)B * bs->nIdx * 16) != hipSuccess) return -3;
+        if (!bs->idxVal3 && hipMalloc(&bs->idxVal3, (size_t)B * bs->nIdx * 8) != hipSuccess) return -3;
         pa.fineIdx = (uint32_t *)bs->fineIdx;
         hipLaunchKernelGGL(k_prune_emit12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
         pruneFrom = D - 13;
@@ -2419,7 +2436,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.blockL1 = bs->blockL1;
     a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
-    a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.nIdx = bs->nIdx;
+    a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.idxVal3 = bs->idxVal3; a.nIdx = bs->nIdx;
     a.chainLut = bs->chainLut;
     const bool quad = !mr && D >= 12 && bs->K >= 2;
     const int64_t nblk = cdiv((int64_t)1 << D, fused ? 4096 : (quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK));
