@@ -401,7 +401,7 @@ def main():
             traffic = pm["decode_traffic_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "k_decode_fine", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "k_decode_quad", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": PMC_TRAFFIC + " (bytes per launch)" if traffic else None,
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(dec_avg_s * 1e3, 4)}

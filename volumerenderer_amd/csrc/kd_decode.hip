@@ -732,15 +732,22 @@ k_decode_fine(TileArgs a)
 //     first '3' are forced to '3' before the lookup, so a leaf's key never depends on its successor's tokens;
 //   * a pruned node is a token that reads as '3' (also forced where an ancestor is pruned): its subtree's voxels take
 //     its parent's scalar through selects, never through exec-mask branches.
+#ifndef QD_WAVES
 #define QD_WAVES 16
+#endif
+#ifndef QD_KEYMASK
+#define QD_KEYMASK 0xFFFCu      // (timing experiments only: a smaller mask fakes a smaller table)
+#endif
 #ifndef QD_TPW
-#define QD_TPW 4            // tiles per wave: amortises the table copy
+#define QD_TPW 16           // tiles per wave: amortises the table copy
 #endif
 #define QD_TS 68            // tile row stride in words (as FD_TS)
 #ifndef QD_PF
 #define QD_PF 4             // steps the stream-word requests run ahead
 #endif
+#ifndef QD_CHAIN_ENTRIES
 #define QD_CHAIN_ENTRIES 16384
+#endif
 
 // entry: byte 0 = A (int8), byte 2 = LO, byte 3 = HI; `levels` = branch levels at or above the cut (7: levelCut at
 // full depth; fewer: progressive cut inside the branch, deeper levels refine nothing)
@@ -786,7 +793,10 @@ __device__ __forceinline__ int qd_leaf(uint32_t yl, int V5, int d6, const uint32
     const int sc = __builtin_amdgcn_sbfe((int)yl, 0, 2);    // code 1 -> +1, 2 -> -2, 3 -> -1
     const int Vc = med3i(mad24i((sc + 1) >> 1, d6, V5), 0, 255);           // R.cpp:783-787
     const uint32_t ym = ones_from(f, yl);                   // the tokens from the first '3' on read as '3'
-    const uint32_t ent = *(const uint32_t *)((const char *)chainS + (ym & 0xFFFCu));   // branch tokens = bits 2..15
+    // branch tokens = bits 2..15.  (Measured on gfx950: a two-operand VALU instruction takes 2 cycles of the SIMD,
+    // a three-operand or byte-select (SDWA) one 4 -- scratch/mb/valu_rate.hip -- so the three byte selects below cost
+    // what six plain instructions would; reading the entry's bytes with three LDS reads instead was 27 % slower.)
+    const uint32_t ent = *(const uint32_t *)((const char *)chainS + (ym & QD_KEYMASK));
     int v = Vc + (int)(int8_t)(ent & 255u);
     v = min(max(v, (int)((ent >> 16) & 255u)), (int)(ent >> 24));
     return v;
@@ -810,7 +820,10 @@ __device__ __forceinline__ uint32_t qd_pair(uint32_t y, uint32_t yh, bool dead, 
     return (uint32_t)v1 | ((uint32_t)v2 << 8);
 }
 
-__global__ void __launch_bounds__(64 * QD_WAVES)
+#ifndef QD_MINW
+#define QD_MINW 1
+#endif
+__global__ void __launch_bounds__(64 * QD_WAVES, QD_MINW)
 k_decode_quad(TileArgs a)
 {
     // one struct: the table sits at LDS address 0, so a lookup's address is the masked key itself
@@ -876,8 +889,11 @@ k_decode_quad(TileArgs a)
         const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
         if (liveMask == 0ull) tile[lane] = val0 * 0x01010101u;          // as in k_decode_tile: one value per block
         else {
-            // ---- park (scalar of its depth-(D-3) parent, tokens it owns) for each 4-leaf subtree of my block; a block
-            // under a pruned node parks its final words
+            // ---- park, for each 4-leaf subtree of my block: the scalar of its depth-(D-3) parent (bits 0-7), the token
+            // offset of its run inside the block's (8-17: prefix sum of the side-car counts, done once here instead of a
+            // DPP scan per step) and whether its root exists (18: it owns more tokens than the ancestors heading its
+            // run -- a pruned ancestor ends the run).  A block under a pruned node parks "no root" with offset 0 at the
+            // stream's first word, or, where its whole step is skipped, the final words.
             const bool deadB = off == VR_IDX_DEAD;
             uint4 cv = make_uint4(0, 0, 0, 0);
             uint2 sv = make_uint2(0, 0);
@@ -885,19 +901,24 @@ k_decode_quad(TileArgs a)
                 cv = *(const uint4 *)(a.fine + io * 16);
                 sv = *(const uint2 *)(a.val3 + io * 8);
             }
-            offS[wave][lane] = off;
+            offS[wave][lane] = deadB ? 0u : off;
             const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, sw[2] = {sv.x, sv.y};
             const uint32_t rep = val0 * 0x01010101u;
+            const bool stepDead = ((uint32_t)(liveMask >> (lane & 60)) & 15u) == 0u;     // my step's four blocks are all dead
+            const uint32_t deadW = stepDead ? rep : val0;
+            uint32_t run = 0;
 #pragma unroll
             for (int gg = 0; gg < 16; ++gg) {
-                const uint32_t w = __builtin_amdgcn_perm(cw[gg >> 2], sw[gg >> 3],
-                                                         0x0c0c0000u | ((4u + (uint32_t)(gg & 3)) << 8) | (uint32_t)((gg >> 1) & 3));
-                tile[gg * QD_TS + lane] = deadB ? rep : w;
+                const uint32_t cgg = (cw[gg >> 2] >> (8 * (gg & 3))) & 255u;
+                const int own = gg == 0 ? 4 : (gg & 1 ? 0 : (gg & 2 ? 1 : (gg & 4 ? 2 : 3)));
+                const uint32_t vgg = (sw[gg >> 3] >> (8 * ((gg >> 1) & 3))) & 255u;
+                const uint32_t w = vgg | (run << 8) | ((uint32_t)(own - (int)cgg) & 0x40000u);
+                tile[gg * QD_TS + lane] = deadB ? deadW : w;
+                run += cgg;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
-            // ---- 16 steps of 4 blocks x 16 lanes.  The stream words of a step are requested QD_PF steps ahead: a step is
-            // ~130 instructions, far shorter than a trip to memory, and with 64 KiB of table a CU holds 16 waves
+            // ---- 16 steps of 4 blocks x 16 lanes.  The stream words of a step are requested QD_PF steps ahead
             uint32_t qw[QD_PF][4], qb[QD_PF], qV[QD_PF];
             bool qLive[QD_PF];
 #pragma unroll
@@ -907,19 +928,11 @@ k_decode_quad(TileArgs a)
                 const int S = 4 * it + (lane >> 4);
                 const uint32_t so = offS[wave][S];
                 const uint32_t tw = tile[g * QD_TS + S];
-                const bool deadRow = so == VR_IDX_DEAD;
-                const uint32_t c = deadRow ? 0u : ((tw >> 8) & 255u);
                 qV[slot] = tw & 255u;
-                uint32_t inc = c;                                   // prefix sum within the row of 16 lanes
-                inc += dpp_u32<0x111, 0xf>(0, inc);
-                inc += dpp_u32<0x112, 0xf>(0, inc);
-                inc += dpp_u32<0x114, 0xf>(0, inc);
-                inc += dpp_u32<0x118, 0xf>(0, inc);
-                const uint32_t tokpos = (deadRow ? 0u : so) + inc - c;
+                const uint32_t tokpos = so + ((tw >> 8) & 1023u);
                 const uint32_t *Wp = W + (tokpos >> 4);
                 qb[slot] = (tokpos & 15u) * 2u;
-                // my root exists <=> I own more tokens than the ancestors heading my run (a pruned ancestor ends the run)
-                qLive[slot] = c > ownN;
+                qLive[slot] = (tw & 0x40000u) != 0u;
                 qw[slot][0] = Wp[0]; qw[slot][1] = Wp[1]; qw[slot][2] = Wp[2]; qw[slot][3] = Wp[3];
             };
 #pragma unroll
