@@ -42,7 +42,7 @@ extern "C" {
 typedef int32_t vr_status;
 enum {
     VR_OK = 0,
-    VR_ERR_INVALID = -1,     /* bad argument (null pointer, non power-of-two dims, negative tolerance ...) */
+    VR_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive dims, negative tolerance ...) */
     VR_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP call failed; there is no CPU fallback */
     VR_ERR_OOM = -3,
     VR_ERR_IO = -4,          /* save/open: file missing or short (reference: exit(-1), R.cpp:560-565) */
@@ -95,9 +95,13 @@ vr_status vr_download(void *dst_host, const void *src_dev, int64_t bytes, void *
 
 /* ---- brickset life cycle ------------------------------------------------------
  * VolumeKdtree(std::vector<byte>&, x, y, z) + setErrorTolerance + setMaxEpochs
- * (VolumeKdtree_recover.h:103-112, R.cpp:9-15).  dims must be powers of two
- * (the reference's brick sizes 256x256x128 / 256^3 are); other extents return
- * VR_ERR_UNSUPPORTED (reference behaviour for them is lossy). */
+ * (VolumeKdtree_recover.h:103-112, R.cpp:9-15).  Any extents are accepted, as in the reference
+ * (R.cpp:26-36: origTreeDepth = the sum of the floors of the three log2; R.cpp:151-162: the split rule that
+ * follows from it -- unequal halves, an axis order that differs from node to node, leaves that read the min
+ * corner of a box of several cells, R.cpp:194-195, and levelCut's boxes that leave some voxels unwritten,
+ * R.cpp:759-766 with 806-833; all reproduced bit for bit).  Power-of-two extents up to 1024 per axis (the
+ * reference's brick sizes 256x256x128 / 256^3) take the tiled fast kernels, everything else table-driven ones.
+ * Limits of one tree: origTreeDepth <= 28 and fewer than 2^31 voxels -> VR_ERR_UNSUPPORTED beyond. */
 vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_t dims[3],
                              int32_t tolerance, int32_t max_epochs, int32_t variant);
 vr_status vr_brickset_destroy(vr_brickset *bs);

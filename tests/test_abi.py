@@ -46,7 +46,7 @@ def test_argument_validation_and_no_cpu_fallback(L):
     assert L.vr_device_count(C.byref(n)) == 0
     h = C.c_void_p()
     dims = (C.c_int64 * 3)(16, 16, 16)
-    bad = (C.c_int64 * 3)(16, 12, 16)
+    bad = (C.c_int64 * 3)(1 << 21, 16, 16)       # an axis beyond 2^20 (or 2^31 voxels and more): unsupported
     assert L.vr_brickset_create(None, 1, dims, 1, 2, 0) == -1           # VR_ERR_INVALID
     assert L.vr_brickset_create(C.byref(h), 1, dims, -1, 2, 0) == -1    # negative tolerance
     assert L.vr_brickset_create(C.byref(h), 1, bad, 1, 2, 0) == -7      # VR_ERR_UNSUPPORTED

@@ -547,3 +547,44 @@ def test_encoder_out_of_memory_is_reported_every_time(vr):
     v = np.random.default_rng(5).integers(0, 256, (32, 32, 32), dtype=np.uint8)
     small.build(v)
     assert small.info(0)["num_active_nodes"] > 0
+
+
+@pytest.mark.parametrize("shape", [(12, 6, 5), (40, 16, 24), (48, 64, 96), (3, 1, 1), (7, 9, 2), (2, 2, 2048)])
+def test_general_extents_match_oracle(vr, oracle, shape, tmp_path):
+    """Extents that are not powers of two (R.cpp:151-162: unequal boxes, a split axis that differs from node to node,
+    leaves of two cells or none, R.cpp:194-195 / 759-766) and axes beyond 1024: tree bytes, distanceMap, statistics
+    and the decoded voxels -- full depth and progressive -- are the oracle's, also through a saved file."""
+    rng = np.random.default_rng(sum(shape))
+    z, y, x = shape
+    for vol, tol, ep in ((rng.integers(0, 256, shape, dtype=np.uint8), 2, 2), (rm_like(shape), 1, 2), (rm_like(shape, 5), 0, 5)):
+        ref, bs = check_case(vr, oracle, vol, tol, ep)
+        D, M = ref.origTreeDepth, ref.maxTreeDepth
+        for cut in sorted({0, 1, D // 2, D - 1, D, D + 2, M - 1}):
+            if 0 <= cut < M:
+                got = bs.decode(cut_depth=cut).cpu().numpy().reshape(shape)
+                assert np.array_equal(got, ref.levelCutProgressive(cut)), cut
+        p = str(tmp_path / "g.bin")
+        bs.save(p)
+        fs = vr.BrickSet.open(p)
+        assert np.array_equal(fs.decode().cpu().numpy().reshape(shape), ref.levelCut())
+    # MidRangeTree on the same geometry
+    vol = rm_like(shape, 9)
+    ref = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=2, guarded=True, midrange=True).build()
+    ms = vr.BrickSet(1, (x, y, z), 1, 2, 2)
+    ms.build(vol.copy())
+    assert np.array_equal(ms.tree(0), ref.tree) and np.array_equal(ms.tree_range(0), ref.tree_range)
+    assert np.array_equal(ms.decode().cpu().numpy().reshape(shape), ref.levelCut())
+
+
+def test_general_extents_big_brick(vr, oracle):
+    """256 x 256 x 96 (z not a power of two: D = 22, most z leaves span one cell, every third pair of them two)."""
+    shape = (96, 256, 256)
+    vol = rm_like(shape, 2)
+    ref, bs = check_case(vr, oracle, vol, 1, 2)
+    # batched: two different bricks of that shape in one set
+    v2 = np.stack([vol, rm_like(shape, 4)])
+    b2 = vr.BrickSet(2, (256, 256, 96), 1, 2).build(v2)
+    dec = b2.decode().cpu().numpy().reshape(2, *shape)
+    assert np.array_equal(dec[0], ref.levelCut())
+    r1 = oracle.OracleTree(v2[1].copy(), tolerance=1, max_epochs=2).build()
+    assert np.array_equal(b2.tree(1), r1.tree) and np.array_equal(dec[1], r1.levelCut())

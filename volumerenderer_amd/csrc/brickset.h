@@ -53,6 +53,16 @@ struct BrickSet {
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
     bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream
     uint32_t *spread = nullptr;  // rank bits of every x, y, z coordinate: rank(x,y,z) = spread[x] | spread[X+y] | spread[X+Y+z]
+    // General extents (any axis not a power of two, or longer than 1024): the reference's split rule (R.cpp:151-162)
+    // then gives boxes of unequal size, an axis order that differs from node to node, leaves that span two cells or
+    // none.  The tree itself is still the complete binary heap of 2^D leaves, so every rank-domain kernel (level loop,
+    // prune, emit, stream parse) runs unchanged; only the two ends that touch voxels go through tables:
+    bool generalGeom = false;
+    uint32_t *srcIdx = nullptr;    // 2^D: voxel a leaf reads, the min corner of its build box (R.cpp:194-195)
+    uint32_t *ownerRank = nullptr; // X*Y*Z: the leaf whose decoded value a voxel ends up with: the last one in preorder
+                                   // whose levelCut box covers it (R.cpp:759-766, 790-799, 821-830)
+    uint8_t *ownerSurv = nullptr;  // X*Y*Z: how many halvings of its leaf's box along a grown branch the voxel survives
+    uint8_t *rankVals = nullptr;   // B * 2^D * 2: decoded value | branch nodes << 8 of every leaf rank (general-extent decode scratch)
 
     std::vector<Ctrl> hostCtrl; // copied back lazily
     uint32_t lutZeroRun = 0;    // chainLut[256]: table entries that would need the zero-run rewrite (always 0)
@@ -76,6 +86,7 @@ int build_index_from_stream(BrickSet *bs, int brick, const uint8_t *treeHost, in
                             const uint8_t *dmapHost, std::vector<uint32_t> &offs, std::vector<uint8_t> &vals,
                             std::vector<uint8_t> &fine, std::vector<uint8_t> &val3);
 void make_geom(Geom &g, const int64_t dims[3]);
+int build_general_geometry(BrickSet *bs);   // srcIdx / ownerRank for general extents (0, -3 out of memory, -1 device error)
 void make_lut(const Geom &g, int K, std::vector<uint32_t> &lut);
 
 } // namespace vr

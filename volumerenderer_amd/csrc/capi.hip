@@ -187,7 +187,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_encoder_buffers(b);
     free_stream2(b.mid);
     free_stream2(b.rng);
-    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.idxVal3); hipFree(b.chainTab); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread);
+    hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.idxVal3); hipFree(b.chainTab); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread); hipFree(b.srcIdx); hipFree(b.ownerRank); hipFree(b.ownerSurv); hipFree(b.rankVals);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     delete h;
     return VR_OK;
@@ -201,8 +201,12 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     if (!out || !dims || num_bricks <= 0) return VR_ERR_INVALID;
     if (tolerance < 0 || max_epochs < 0 || variant < 0 || variant > 2) return VR_ERR_INVALID;
     for (int k = 0; k < 3; ++k) if (dims[k] <= 0) return VR_ERR_INVALID;
-    if (!pow2(dims[0]) || !pow2(dims[1]) || !pow2(dims[2])) return VR_ERR_UNSUPPORTED;
-    if (dims[0] > 1024 || dims[1] > 1024 || dims[2] > 1024) return VR_ERR_UNSUPPORTED;
+    // power-of-two extents up to 1024 per axis take the tiled kernels; anything else (the reference accepts any
+    // extents, R.cpp:26-36,151-162) goes through the general-extent tables.  One tree holds at most 2^28 leaves and
+    // 2^31 voxels here (32-bit ranks, voxel indices and token offsets).
+    const bool general = !pow2(dims[0]) || !pow2(dims[1]) || !pow2(dims[2]) || dims[0] > 1024 || dims[1] > 1024 || dims[2] > 1024;
+    if (dims[0] > (1ll << 20) || dims[1] > (1ll << 20) || dims[2] > (1ll << 20) || dims[0] * dims[1] * dims[2] >= (1ll << 31))
+        return VR_ERR_UNSUPPORTED;
     if (!device_ok()) return VR_ERR_NO_DEVICE;
     vr_brickset *h = new (std::nothrow) vr_brickset();
     if (!h) return VR_ERR_OOM;
@@ -211,6 +215,7 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     make_geom(b.g, dims);
     b.D = b.g.D;
     if (b.D > 28) { delete h; return VR_ERR_UNSUPPORTED; }
+    b.generalGeom = general;
     b.maxDepth = b.D + VR_CHAIN_LEVELS;
     b.tolerance = tolerance; b.maxEpochs = max_epochs; b.variant = variant;
     b.K = b.D < 6 ? b.D : 6;   // decode index granularity: 4x4x4 voxel subtrees
@@ -226,14 +231,18 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
         hipError_t e = hipMalloc(&b.idxOff, (size_t)b.B * b.nIdx * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&b.idxVal, (size_t)b.B * b.nIdx);
         if (e == hipSuccess) e = hipMalloc(&b.idxValCut, (size_t)b.B * b.nIdx);
+        if (e == hipSuccess && general) {
+            const int grc = build_general_geometry(&b);
+            if (grc != 0) e = grc == -3 ? hipErrorOutOfMemory : hipErrorUnknown;
+        }
         if (e == hipSuccess) e = hipMalloc(&b.lut, ((size_t)1 << b.K) * sizeof(uint32_t));
-        if (e == hipSuccess) {
+        if (e == hipSuccess && !general) {
             std::vector<uint32_t> lut;
             make_lut(b.g, b.K, lut);
             e = hipMemcpy(b.lut, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
-        if (e == hipSuccess) e = hipMalloc(&b.spread, (size_t)(b.g.X + b.g.Y + b.g.Z) * sizeof(uint32_t));
-        if (e == hipSuccess) {
+        if (e == hipSuccess && !general) e = hipMalloc(&b.spread, (size_t)(b.g.X + b.g.Y + b.g.Z) * sizeof(uint32_t));
+        if (e == hipSuccess && !general) {
             // kernels never walk Geom::axis/bit (a dependent chain of loads from the kernel-argument
             // segment): a coordinate's contribution to the Morton rank comes from this table
             std::vector<uint32_t> sp((size_t)(b.g.X + b.g.Y + b.g.Z), 0u);

@@ -28,8 +28,10 @@ void make_geom(Geom &g, const int64_t dims[3])
     g.voxels = dims[0] * dims[1] * dims[2];
     int64_t ext[3] = {dims[0], dims[1], dims[2]};
     for (int k = 0; k < 3; ++k) { int n = 0; while (((int64_t)1 << (n + 1)) <= dims[k]) ++n; g.nb[k] = n; }
-    g.D = g.nb[0] + g.nb[1] + g.nb[2];
-    for (int d = 0; d < g.D; ++d) {            // split-axis rule, R.cpp:151-159
+    g.D = g.nb[0] + g.nb[1] + g.nb[2];         // R.cpp:26-29 (floor of the logarithms)
+    // axis[] / bit[]: the per-depth split axis.  Only meaningful for power-of-two extents, where every node of a
+    // depth splits the same axis; general extents go through BrickSet::srcIdx / ownerRank instead.
+    for (int d = 0; d < g.D && d < 32; ++d) {  // split-axis rule, R.cpp:151-159
         int sd = d % 3, i = 0;
         while (ext[0] * ext[1] * ext[2] > 1 && ext[sd] == 1) sd = (d + ++i) % 3;
         ext[sd] /= 2;
@@ -37,6 +39,102 @@ void make_geom(Geom &g, const int64_t dims[3])
         g.axis[d] = (uint8_t)sd;
         g.bit[d] = (uint8_t)b;                 // the coordinate bit this split decides
     }
+}
+
+// ---- general extents: the two geometry tables (BrickSet::srcIdx, ownerRank) ------------------------------------
+// Walks of the reference's own box arithmetic, one thread per leaf / per voxel.  Split sizes do not depend on the
+// box position ((2 min + e) / 2 = min + e / 2), but the axis does depend on the node: "while the box has more than
+// one cell and extent 1 on the axis, take the next axis" (R.cpp:151-159).
+struct Box3 { int lo[3], hi[3]; };
+__device__ __forceinline__ int split_axis(const Box3 &b, int depth, bool &more)
+{
+    const long long e0 = b.hi[0] - b.lo[0], e1 = b.hi[1] - b.lo[1], e2 = b.hi[2] - b.lo[2];
+    more = e0 * e1 * e2 > 1;
+    int sd = depth % 3, i = 0;
+    while (more && (b.hi[sd] - b.lo[sd]) == 1) sd = (depth + ++i) % 3;
+    return sd;
+}
+
+// buildRecursive's boxes (R.cpp:143-201): a node of one cell still "splits" -- its left child gets an empty box, its
+// right child the cell -- and a leaf reads the voxel at its box's min corner whatever the box holds (R.cpp:194-195)
+__global__ void __launch_bounds__(256)
+k_geom_src(int X, int Y, int Z, int D, uint32_t *__restrict__ src)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if ((unsigned long long)r >= (1ull << D)) return;
+    Box3 b = {{0, 0, 0}, {X, Y, Z}};
+    for (int d = 0; d < D; ++d) {
+        bool more;
+        const int sd = split_axis(b, d, more);
+        const int mid = (b.lo[sd] + b.hi[sd]) / 2;
+        if ((r >> (D - 1 - d)) & 1u) b.lo[sd] = mid; else b.hi[sd] = mid;
+    }
+    src[r] = (uint32_t)b.lo[0] + (uint32_t)X * ((uint32_t)b.lo[1] + (uint32_t)Y * (uint32_t)b.lo[2]);
+}
+
+// levelCut's boxes (R.cpp:790-799, 821-830): a box of one cell is handed to BOTH children unsplit, so below it the
+// same cell is written once per leaf and the last leaf in preorder -- all the way right -- wins; a box of more cells
+// is split like the encoder's.  Pruned nodes write their whole box: the same value for every leaf rank below them.
+// The walk does not stop at the leaves: a grown branch's nodes are "left children" too (R.cpp:806-833), so a leaf box
+// of several cells is halved again at every branch level and only what is left at the branch's LAST node is written;
+// the other cells of the box keep the zero of the freshly sized output vector (R.cpp:733, SURVEY C-10).
+// surv[v] = how many of those halvings (from depth D on) voxel v survives (255: all of them).
+__global__ void __launch_bounds__(256)
+k_geom_owner(int X, int Y, int Z, int D, uint32_t *__restrict__ owner, uint8_t *__restrict__ surv)
+{
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= (long long)X * Y * Z) return;
+    const int c[3] = {(int)(v % X), (int)((v / X) % Y), (int)(v / ((long long)X * Y))};
+    Box3 b = {{0, 0, 0}, {X, Y, Z}};
+    uint32_t r = 0;
+    for (int d = 0; d < D; ++d) {
+        bool more;
+        const int sd = split_axis(b, d, more);
+        uint32_t bit = 1u;
+        if (more) {
+            const int mid = (b.lo[sd] + b.hi[sd]) / 2;
+            bit = c[sd] >= mid ? 1u : 0u;
+            if (bit) b.lo[sd] = mid; else b.hi[sd] = mid;
+        }
+        r = (r << 1) | bit;
+    }
+    owner[v] = r;
+    int sv = 255;
+    for (int j = 0; j < VR_CHAIN_LEVELS; ++j) {
+        bool more;
+        const int sd = split_axis(b, D + j, more);
+        if (!more) break;                       // one cell left: mine, for every further level
+        const int mid = (b.lo[sd] + b.hi[sd]) / 2;
+        if (c[sd] >= mid) { sv = j; break; }    // the (j+1)-th halving drops me
+        b.hi[sd] = mid;
+    }
+    surv[v] = (uint8_t)sv;
+}
+
+int build_general_geometry(BrickSet *bs)
+{
+    const Geom &g = bs->g;
+    const size_t nLeaf = (size_t)1 << g.D;
+    if (hipMalloc(&bs->srcIdx, nLeaf * sizeof(uint32_t)) != hipSuccess) return -3;
+    if (hipMalloc(&bs->ownerRank, (size_t)g.voxels * sizeof(uint32_t)) != hipSuccess) return -3;
+    if (hipMalloc(&bs->ownerSurv, (size_t)g.voxels) != hipSuccess) return -3;
+    hipLaunchKernelGGL(k_geom_src, dim3((unsigned)((nLeaf + 255) / 256)), dim3(256), 0, 0, g.X, g.Y, g.Z, g.D, bs->srcIdx);
+    hipLaunchKernelGGL(k_geom_owner, dim3((unsigned)((g.voxels + 255) / 256)), dim3(256), 0, 0, g.X, g.Y, g.Z, g.D, bs->ownerRank, bs->ownerSurv);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return launch_status("geometry");
+}
+
+// out[voxel] = value of the leaf rank that owns it, if the box its terminal node writes still holds the voxel
+// (rankVals: value | branch nodes below the leaf << 8; 0 branch nodes = the leaf or an ancestor is pruned: whole box)
+__global__ void __launch_bounds__(256)
+k_owner_gather(const uint16_t *__restrict__ rankVals, int64_t leafStride, const uint32_t *__restrict__ owner,
+               const uint8_t *__restrict__ surv, int64_t voxels, uint8_t *__restrict__ out)
+{
+    const int brick = blockIdx.y;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= voxels) return;
+    const uint32_t e = rankVals[(int64_t)brick * leafStride + owner[v]];
+    out[(int64_t)brick * voxels + v] = (e >> 8) <= (uint32_t)surv[v] ? (uint8_t)e : (uint8_t)0;
 }
 
 // local rank inside a depth-(D-K) subtree -> packed voxel offset (dx | dy<<10 | dz<<20)
@@ -69,7 +167,9 @@ struct DecodeArgs {
     const uint8_t *idxValCut;   // cut < Ds: scalar of every subtree's ancestor at depth `cut`
 };
 
-// v1: one lane per subtree, direct byte stores.
+// v1: one lane per subtree, direct byte stores.  RANK_OUT: the value of every leaf RANK goes to a.out (B * 2^D bytes,
+// general extents: k_owner_gather then hands the voxels their owners' values) instead of the voxels themselves.
+template <bool RANK_OUT>
 __global__ void __launch_bounds__(64)
 k_decode_lane(DecodeArgs a)
 {
@@ -81,13 +181,16 @@ k_decode_lane(DecodeArgs a)
     const uint8_t *dmapG = a.ctrls[brick].distanceMap;
     uint8_t dmap[VR_MAX_DEPTH + 8];
     for (int q = 0; q <= a.D + VR_CHAIN_LEVELS; ++q) dmap[q] = q > a.cut ? 0 : dmapG[q];   // no refinement below the cut
-    int ox, oy, oz;
-    rank_to_xyz(a.g, (uint32_t)(s << a.K), ox, oy, oz);
-    uint8_t *O = a.out + (int64_t)brick * a.g.voxels + ox + (int64_t)a.g.X * (oy + (int64_t)a.g.Y * oz);
+    int ox = 0, oy = 0, oz = 0;
+    if (!RANK_OUT) rank_to_xyz(a.g, (uint32_t)(s << a.K), ox, oy, oz);
+    uint8_t *O = RANK_OUT ? a.out + 2 * ((int64_t)brick * ((int64_t)1 << a.D) + (s << a.K))
+                          : a.out + (int64_t)brick * a.g.voxels + ox + (int64_t)a.g.X * (oy + (int64_t)a.g.Y * oz);
     const int64_t sy = a.g.X, sz = (int64_t)a.g.X * a.g.Y;
     const int K = a.K;
+    int branchNodes = 0;      // RANK_OUT: nodes of the grown branch below the leaf being written (0: pruned at or above it)
     auto fill = [&](uint32_t lo, uint32_t cnt, int v) {
         for (uint32_t lr = lo; lr < lo + cnt; ++lr) {
+            if (RANK_OUT) { ((uint16_t *)O)[lr] = (uint16_t)(v | (branchNodes << 8)); continue; }
             uint32_t p = a.lut[lr];
             O[(p & 1023u) + sy * ((p >> 10) & 1023u) + sz * (p >> 20)] = (uint8_t)v;
         }
@@ -106,13 +209,15 @@ k_decode_lane(DecodeArgs a)
         bool terminal = false;
         if (tok == 3) { fill(path << (K - j), 1u << (K - j), v); terminal = true; }
         else if (j == K) {
+            branchNodes = VR_CHAIN_LEVELS;
             for (int c = 1; c <= VR_CHAIN_LEVELS; ++c) {   // grown branch: same voxel, distances 64..1
                 int t2 = (W[pos >> 4] >> ((pos & 15u) * 2u)) & 3u;
                 ++pos;
-                if (t2 == 3) break;
+                if (t2 == 3) { branchNodes = c; break; }
                 v = apply_code(v, t2, dmap[a.D + c]);
             }
             fill(path, 1, v);
+            branchNodes = 0;
             terminal = true;
         }
         if (terminal) {
@@ -1029,7 +1134,19 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         if (rangeStream) idxVals = bs->idxValCut;
     }
     TileArgs t;
-    if (!getenv("VRHIP_DECODE_V1") && tile_geometry(bs, t)) {
+    if (bs->generalGeom) {
+        // general extents: rank-domain decode, then every voxel takes its owner leaf's value
+        if (!bs->rankVals && hipMalloc(&bs->rankVals, (size_t)bs->B * bs->leafStride * 2) != hipSuccess) return -3;
+        DecodeArgs a;
+        a.tree = sm.tree; a.treeCap = bs->treeCap;
+        a.idxOff = bs->idxOff; a.idxVal = idxVals; a.nIdx = bs->nIdx;
+        a.ctrls = sm.ctrl; a.lut = nullptr; a.out = bs->rankVals; a.g = bs->g;
+        a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
+        a.cut = cut; a.idxValCut = cutVals;
+        hipLaunchKernelGGL(k_decode_lane<true>, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_owner_gather, dim3((unsigned)((bs->g.voxels + 255) / 256), bs->B), dim3(256), 0, st,
+                           (const uint16_t *)bs->rankVals, bs->leafStride, bs->ownerRank, bs->ownerSurv, bs->g.voxels, out);
+    } else if (!getenv("VRHIP_DECODE_V1") && tile_geometry(bs, t)) {
         t.tree = sm.tree; t.treeCap = bs->treeCap;
         t.idxOff = bs->idxOff; t.idxVal = idxVals; t.nIdx = bs->nIdx;
         t.ctrls = sm.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
@@ -1072,7 +1189,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         a.ctrls = sm.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
         a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
         a.cut = cut; a.idxValCut = cutVals;
-        hipLaunchKernelGGL(k_decode_lane, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_decode_lane<false>, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
     }
     hipEventRecord(bs->ev[6], st);
     return launch_status("decode");

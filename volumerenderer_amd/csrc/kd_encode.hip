@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256)
 k_pyramid(Geom g, int dLeaf, int L, const uint8_t *__restrict__ vox, const uint8_t *__restrict__ inMin,
           const uint8_t *__restrict__ inMax, int64_t inStride, uint8_t *__restrict__ temp, int64_t heapStride,
           uint8_t *__restrict__ tempRange, uint8_t *__restrict__ outMin, uint8_t *__restrict__ outMax,
-          int64_t outStride)
+          int64_t outStride, const uint32_t *__restrict__ srcIdx)
 {
     __shared__ uint8_t smn[2][1024], smx[2][1024];
     const int brick = blockIdx.y;
@@ -47,9 +47,14 @@ k_pyramid(Geom g, int dLeaf, int L, const uint8_t *__restrict__ vox, const uint8
         uint32_t r = base + i;
         uint8_t mn, mx;
         if (FROM_VOXELS) {
-            int x, y, z;
-            rank_to_xyz(g, r, x, y, z);
-            uint8_t v = vox[(int64_t)brick * g.voxels + x + (int64_t)g.X * (y + (int64_t)g.Y * z)];
+            int64_t vi;
+            if (srcIdx) vi = srcIdx[r];            // general extents: the min corner of the leaf's box (BrickSet::srcIdx)
+            else {
+                int x, y, z;
+                rank_to_xyz(g, r, x, y, z);
+                vi = x + (int64_t)g.X * (y + (int64_t)g.Y * z);
+            }
+            uint8_t v = vox[(int64_t)brick * g.voxels + vi];
             mn = mx = v;
             T[((int64_t)1 << dLeaf) + r] = v;       // leaf: (v+v)/2 = v  (R.cpp:194-198)
             if (TR) TR[((int64_t)1 << dLeaf) + r] = 0; // half range of a single voxel (M.cpp:235)
@@ -2327,7 +2332,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         int64_t inStride = 0;
         const int64_t oStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
         Pyr12Geom pg{};
-        bool use12 = D >= 12;
+        bool use12 = D >= 12 && !bs->generalGeom;
         if (use12) {
             for (int q = 0; q < 12; ++q) {
                 const int ax = bs->g.axis[D - 12 + q];
@@ -2365,11 +2370,11 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
             if (round == 0)
                 hipLaunchKernelGGL(k_pyramid<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, bs->g, dLeaf, L, vox,
                                    inMin, inMax, inStride, bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr,
-                                   oMin, oMax, oStride);
+                                   oMin, oMax, oStride, bs->generalGeom ? bs->srcIdx : nullptr);
             else
                 hipLaunchKernelGGL(k_pyramid<false>, dim3((unsigned)nblk, B), dim3(256), 0, st, bs->g, dLeaf, L, vox,
                                    inMin, inMax, inStride, bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr,
-                                   oMin, oMax, oStride);
+                                   oMin, oMax, oStride, nullptr);
             dLeaf -= L;
             rootMinP = oMin; rootMaxP = oMax;
             if (dLeaf == 0) break;
