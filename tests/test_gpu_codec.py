@@ -588,3 +588,28 @@ def test_general_extents_big_brick(vr, oracle):
     assert np.array_equal(dec[0], ref.levelCut())
     r1 = oracle.OracleTree(v2[1].copy(), tolerance=1, max_epochs=2).build()
     assert np.array_equal(b2.tree(1), r1.tree) and np.array_equal(dec[1], r1.levelCut())
+
+
+@pytest.mark.parametrize("shape,tol,ep", [((128, 256, 256), 1, 2), ((16, 16, 256), 2, 3), ((8, 16, 128), 6, 5), ((16, 32, 64), 0, 2)])
+def test_midrange_on_the_fused_kernels(vr, oracle, shape, tol, ep):
+    """MidRangeTree through k_prune_emit12 / k_concat12 (second launch for the range stream, M.cpp:871-982) and the
+    mid stream through k_decode_quad: both 2-bit streams, both distanceMaps, the 4-bit packing (M.cpp:1095-1128), the
+    decoded voxels and the decoded half-range stream against the oracle -- at the bench brick size and on volumes with
+    saturated ends (branches the table does not cover) and pruned boxes of every size."""
+    rng = np.random.default_rng(shape[0] + tol)
+    z, y, x = shape
+    vols = [rm_like(shape, 7)] if shape[0] == 128 else [_mixed_volume(rng, shape) for _ in range(3)] + [rng.integers(0, 256, shape, dtype=np.uint8)]
+    for vol in vols:
+        ref = oracle.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep, midrange=True, guarded=True).build()
+        bs = vr.BrickSet(1, (x, y, z), tol, ep, 2)
+        bs.build(vol.copy())
+        assert bs.info(0)["num_active_nodes"] == ref.numActiveNodes
+        assert list(bs.distance_map(0)) == list(ref.distanceMap) and list(bs.distance_map_range(0)) == list(ref.distanceMap_range)
+        assert np.array_equal(bs.tree(0), ref.tree)
+        assert np.array_equal(bs.tree_range(0), ref.tree_range)
+        assert np.array_equal(bs.packed4(0), ref.convertToByteArray())
+        assert np.array_equal(bs.decode().cpu().numpy().reshape(shape), ref.levelCut())
+        D = ref.origTreeDepth
+        for cut in (None, D, D - 6, 4):
+            got = bs.decode_range(cut_depth=-1 if cut is None else cut).cpu().numpy().reshape(shape)
+            assert np.array_equal(got, ref.levelCutRange(cut)), cut

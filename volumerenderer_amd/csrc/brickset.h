@@ -35,7 +35,7 @@ struct BrickSet {
     int64_t estSummStride = 0;
     unsigned long long *blockL1 = nullptr; // B * nEmitBlk
     uint8_t *blockAlive = nullptr, *blockVal = nullptr;   // B * nEmitBlk
-    unsigned long long *blockSpine = nullptr; // B * nEmitBlk
+    unsigned long long *blockSpine = nullptr, *blockSpineR = nullptr; // B * nEmitBlk (R: MidRangeTree's range stream)
     uint32_t *chainLut = nullptr;   // 256: grown branch of a leaf by its initial error (k_chain_lut)
     uint32_t *blockTot = nullptr, *blockOff = nullptr; // B * nEmitBlk
     int64_t nEmitBlk = 0;

@@ -130,7 +130,7 @@ static void free_encoder_buffers(BrickSet &b)
         for (int i = 0; i < 3; ++i) drop(s->recon[i]);
     }
     for (int i = 0; i < 2; ++i) { drop(b.mmMin[i]); drop(b.mmMax[i]); }
-    drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine);
+    drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine); drop(b.blockSpineR);
     drop(b.chainLut); drop(b.blockTot); drop(b.blockOff);
     b.encoderReady = false;
 }
@@ -162,6 +162,7 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.blockAlive, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockVal, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockSpine, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
+    if (b.variant == VR_VARIANT_MIDRANGE) HIPCHK(hipMalloc(&b.blockSpineR, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&b.chainLut, 260 * sizeof(uint32_t)));   // 256 entries + [256]: entries that would need the zero-run rewrite
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));

@@ -1326,6 +1326,7 @@ struct EmitArgs {
     unsigned long long *blockL1;   // per-block sum |recon - temp| after growth (reduced by k_emit_stats)
     uint8_t *blockAlive, *blockVal; // k_block_alive: flags, scalar above the block
     unsigned long long *blockSpine; // k_block_alive: tokens above depth D-10 owned by the block's first rank
+    unsigned long long *blockSpineR; // ... the same tokens of MidRangeTree's range stream
     int64_t nEmitBlk;
     uint8_t *tree, *treeR;
     int64_t treeCap;
@@ -1387,6 +1388,10 @@ struct PruneEmitArgs {
     uint32_t *idxOff;              // block-local token offset of every depth-Ds node (k_concat12 makes it global)
     int64_t nIdx;
     uint32_t *fineIdx;             // 16 bytes per depth-Ds node: tokens owned by each of its 4-leaf subtrees (k_decode_fine)
+    // MidRangeTree's second stream (k_prune_emit12<true>): its own truths, codes, reconstruction, control blocks
+    Ctrl *ctrlsR;
+    uint8_t *tempR, *codesR;
+    ReconBufs rbR;
 };
 
 // The three 4 KiB pieces of a block's staging area, resolved once per thread: indexing ReconBufs (a kernel
@@ -1418,7 +1423,14 @@ __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned lo
     if (hi) atomicOr(&W[w + 2], hi);
 }
 
-__global__ void __launch_bounds__(256, 6)
+// RANGE (MidRangeTree, M.cpp:864-865, 871-982): the half-range stream has the mid stream's STRUCTURE -- a node is
+// pruned, a branch grows and ends exactly where the mid stream's does -- and its own token VALUES: its level-loop codes,
+// and along a branch encodeNode against its own reconstruction (M.cpp:930-933).  The second launch recomputes the mid
+// stream's prune decisions and branch lengths from the mid arrays (same code, so the same result), swaps the range
+// stream's values in, and writes the same string shape into the range stream's staging area.  Index, counts and
+// statistics belong to the first launch.
+template <bool RANGE>
+__global__ void __launch_bounds__(256, RANGE ? 4 : 6)
 k_prune_emit12(PruneEmitArgs a)
 {
     __shared__ uint32_t lutS[256];
@@ -1446,6 +1458,21 @@ k_prune_emit12(PruneEmitArgs a)
     const uint32_t cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
     const uint4 tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
     const uint4 rv = *(const uint4 *)((cPar == 0 ? a.rb.b[0] : (cPar == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+    // RANGE: the same pieces of the range stream
+    uint8_t *CbR = RANGE ? a.codesR + (int64_t)brick * a.codeStride : nullptr;
+    uint32_t upBR = 0, c4BR = 0, c3BR = 0, c2BR = 0, c1HR = 0, cpkR = 0;
+    uint4 tvR = make_uint4(0, 0, 0, 0), rvR = make_uint4(0, 0, 0, 0);
+    int cRaR = 0, cRbR = 0;
+    if (RANGE) {
+        const Ctrl &cr = a.ctrlsR[brick];
+        const int cParR = cr.par;
+        cRaR = cr.ra; cRbR = cr.rb;
+        upBR = CbR[niU >> 2]; c4BR = CbR[n4 >> 2]; c3BR = CbR[n3 >> 2]; c2BR = CbR[n2 >> 2];
+        c1HR = *(const uint16_t *)(CbR + (n1 >> 2));
+        cpkR = *(const uint32_t *)(CbR + (li >> 2));
+        tvR = *(const uint4 *)(a.tempR + (int64_t)brick * a.heapStride + li);
+        rvR = *(const uint4 *)((cParR == 0 ? a.rbR.b[0] : (cParR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+    }
     lutS[t] = lutV;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
     for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
@@ -1453,9 +1480,19 @@ k_prune_emit12(PruneEmitArgs a)
     // its string is the single token 3, its index entries are "pruned", its statistics zero.  Only the root's code
     // is written back: nothing reads the codes below a pruned node for anything but their (equal) scalars.
     const bool plain = tol >= 1 && cpk == 0u && tv.x == rv.x && tv.y == rv.y && tv.z == rv.z && tv.w == rv.w;
+    // (RANGE: the first launch has already turned such a block's root into a 3)
+    const uint32_t upC = (upB >> ((int)(niU & 3) * 2)) & 3u;
     const uint32_t myCodes = ((c4B >> ((int)(n4 & 3) * 2)) & 3u) | ((c3B >> ((int)(n3 & 3) * 2)) & 15u) | c2B | c1H |
-                             ((upB >> ((int)(niU & 3) * 2)) & 3u);
+                             ((RANGE && hU == 1 && upC == 3u) ? 0u : upC);
     if (__syncthreads_and(plain && myCodes == 0u)) {
+        if (RANGE) {        // the range stream's copy of that one token
+            if (t == 0) {
+                cset3(CbR, ((int64_t)1 << (D - 12)) + blk);
+                const PeStage stg = pe_stage_of(a.tempR, a.heapStride, a.rbR, cRaR, cRbR, a.leafStride, brick, blk);
+                *pe_stage(stg, 0) = 3u;
+            }
+            return;
+        }
         if (t == 0) {
             cset3(Cb, ((int64_t)1 << (D - 12)) + blk);
             a.subTok[(int64_t)brick * a.nEmitBlk + blk] = 1;
@@ -1542,16 +1579,48 @@ k_prune_emit12(PruneEmitArgs a)
                 anyAct |= go;
             }
         }
-        if (keepEnd) atomicAdd(&c.zeroRun, (int)((keepEnd & 1u) + ((keepEnd >> 16) & 1u)));
+        if (!RANGE && keepEnd) atomicAdd(&c.zeroRun, (int)((keepEnd & 1u) + ((keepEnd >> 16) & 1u)));
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) { mxA = __builtin_elementwise_max(mxA, pk_s(m[jj])); l1p += pk_s(m[jj]); }
     }
-    {   // statistics (R.cpp:71-76, 115-129): one record per wave = 1024 leaves
+    if (!RANGE) {   // statistics (R.cpp:71-76, 115-129): one record per wave = 1024 leaves
         const int maxErr = wave_max_i32_dpp(max((int)mxB.x, (int)mxB.y)), maxAfter = wave_max_i32_dpp(max((int)mxA.x, (int)mxA.y));
         const unsigned long long l1w = (uint32_t)__builtin_amdgcn_readlane(
             (int)wave_incl_scan_add_dpp((uint32_t)((int)l1p.x + (int)l1p.y)), 63);       // < 2^18 per wave
         if ((t & 63) == 0)
             a.blockL1[(int64_t)brick * a.nEmitBlk + (size_t)blk * 4 + (t >> 6)] = stat_pack(l1w, maxErr, maxAfter);
+    }
+    // ---- RANGE: the leaves' tokens in the range stream.  A pruned leaf is a 3 there too (M.cpp:864-865); a live one
+    // carries its own level-loop code, then as many branch nodes as the mid stream's branch has, each encodeNode
+    // against the range stream's own reconstruction with the same distances (M.cpp:930-933), then the mid stream's
+    // terminator if it has one
+    uint32_t LbR[8];
+    if (RANGE) {
+        const uint32_t twR[4] = {tvR.x, tvR.y, tvR.z, tvR.w}, rwR[4] = {rvR.x, rvR.y, rvR.z, rvR.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t both = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int leaf = 2 * j + e;
+                const uint32_t midStr = (Lb[j] >> (16 * e)) & 0xFFFFu;
+                const int n = (int)((nt[j] >> (16 * e)) & 0xFFFFu) - 1;          // branch tokens of the mid stream
+                const bool prunedLeaf = (midStr & 3u) == 3u;
+                const bool hasTerm = n > 0 && ((midStr >> (2 * n)) & 3u) == 3u;
+                const int k = n - (hasTerm ? 1 : 0);                               // evaluated branch nodes
+                uint32_t bits = prunedLeaf ? 3u : ((cpkR >> (2 * leaf)) & 3u);
+                const int tR = (int)((twR[leaf >> 2] >> (8 * (leaf & 3))) & 255u);
+                int recR = (int)((rwR[leaf >> 2] >> (8 * (leaf & 3))) & 255u);
+#pragma unroll
+                for (int i = 0; i < VR_CHAIN_LEVELS; ++i) {
+                    const Enc en = encode_node(tR, recR, 64 >> i);
+                    if (i < k) { recR = en.recon; bits |= (uint32_t)en.code << (2 * i + 2); }
+                }
+                if (hasTerm) bits |= 3u << (2 * k + 2);
+                both |= bits << (16 * e);
+            }
+            LbR[j] = both;
+        }
     }
     // ---- depths D-1 .. D-4 of my 16 leaves, in registers (R.cpp:596-629: a node only depends on its children)
     uint32_t a1 = c1H, a2 = c2B, f1 = 0, f2 = 0, f3m = 0;      // new codes (2 bits each), pruned-token flags
@@ -1607,19 +1676,37 @@ k_prune_emit12(PruneEmitArgs a)
         }
         __syncthreads();
     }
+    // RANGE: from here on the token VALUES are the range stream's: its own codes, 3 wherever the mid stream pruned
+    // (M.cpp:864-865); the shape (which tokens exist) is unchanged because a token is 3 in both streams or in neither
+    if (RANGE) {
+        const auto merge = [](uint32_t mid, uint32_t rng) { const uint32_t m3 = (mid & (mid >> 1) & 0x55555555u) * 3u; return (rng & ~m3) | m3; };
+        a1 = merge(a1, c1HR) & 0xFFFFu;
+        a2 = merge(a2, c2BR) & 0xFFu;
+        a3 = merge(a3, (c3BR >> ((int)(n3 & 3) * 2)) & 15u) & 15u;
+        a4 = merge(a4, (c4BR >> ((int)(n4 & 3) * 2)) & 3u) & 3u;
+        const uint8_t ro = (uint8_t)((upBR >> ((int)(niU & 3) * 2)) & 3u);
+        const uint8_t mc = codeH[t];
+        __syncthreads();
+        codeOldH[t] = ro;
+        codeH[t] = mc == 3 ? (uint8_t)3 : ro;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Lb[j] = LbR[j];
+        __syncthreads();
+    }
+    uint8_t *Cw = RANGE ? CbR : Cb;
     // the BFS codes are read again only down to depth Ds = D-6 (upper prune levels, k_block_alive, k_concat12's
     // index values, progressive cuts): write back depths D-12 .. D-5; below that they are dead from here on
     if (t >= 1 && t < 64) {                               // heap bytes 1..63 <-> heap nodes 4..255 (whole bytes are mine)
         const int h = t * 4, lq = 31 - __clz(h);
         const uint8_t pk = (uint8_t)(codeH[h] | (codeH[h + 1] << 2) | (codeH[h + 2] << 4) | (codeH[h + 3] << 6));
         const uint8_t po = (uint8_t)(codeOldH[h] | (codeOldH[h + 1] << 2) | (codeOldH[h + 2] << 4) | (codeOldH[h + 3] << 6));
-        if (pk != po) Cb[(((int64_t)1 << (D - 12 + lq)) + ((int64_t)blk << lq) + (h - (1 << lq))) >> 2] = pk;
+        if (pk != po) Cw[(((int64_t)1 << (D - 12 + lq)) + ((int64_t)blk << lq) + (h - (1 << lq))) >> 2] = pk;
     }
     if (t >= 1 && t < 4 && codeH[t] != codeOldH[t]) {     // heap nodes 1..3 share bytes with neighbouring blocks
         const int lq = 31 - __clz(t);
-        cset3(Cb, ((int64_t)1 << (D - 12 + lq)) + ((int64_t)blk << lq) + (t - (1 << lq)));
+        cset3(Cw, ((int64_t)1 << (D - 12 + lq)) + ((int64_t)blk << lq) + (t - (1 << lq)));
     }
-    if (t == 0) a.subTok[(int64_t)brick * a.nEmitBlk + blk] = cntH[1];
+    if (!RANGE && t == 0) a.subTok[(int64_t)brick * a.nEmitBlk + blk] = cntH[1];
     // ---- top-down: the block's own token string, root assumed live.  Thread t owns the live nodes whose
     // first leaf is its first leaf: ancestors at in-block level lq (depth D-12+lq) when t % 2^(8-lq) == 0
     const int jmin = t ? 8 - (__ffs(t) - 1) : 0;
@@ -1675,9 +1762,9 @@ k_prune_emit12(PruneEmitArgs a)
         }
         pe_put(W, bitpos, pb, pn);
     }
-    if ((t & 3) == 0)       // decode side-car index: the depth-Ds node of every 64 leaves, block-local for now
+    if (!RANGE && (t & 3) == 0)       // decode side-car index: the depth-Ds node of every 64 leaves, block-local for now
         a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + (t >> 2)] = aliveAtDs ? pos + (uint32_t)preDs : VR_IDX_DEAD;
-    {
+    if (!RANGE) {
         // ... and, below it, how many tokens each 4-leaf subtree owns in preorder: its own nodes plus the
         // ancestors (depth >= Ds) whose first leaf is its first leaf.  One byte each (at most 4 + 39 tokens); the
         // decoder turns them into token offsets with a 16-lane prefix sum, so one lane decodes four voxels.
@@ -1692,7 +1779,8 @@ k_prune_emit12(PruneEmitArgs a)
     }
     __syncthreads();
     const uint32_t nw = (tot + 15u) >> 4;
-    const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
+    const PeStage stg = RANGE ? pe_stage_of(a.tempR, a.heapStride, a.rbR, cRaR, cRbR, a.leafStride, brick, blk)
+                              : pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
     // piece by piece (three 4 KiB areas): a per-word choice between three 64-bit pointers cost more than the copy
 #pragma unroll 1
     for (uint32_t k = 0; k * 256u < nw; ++k) {          // four trips per piece: the piece is uniform in a trip
@@ -1993,7 +2081,8 @@ k_block_alive(EmitArgs a, int64_t nblk, int sub)     // sub: log2 of the leaves 
     const int dl = a.D - sub;
     bool alive = true;
     int val = dmap[0];                       // decoded scalar along the path (root: R.cpp:743)
-    unsigned long long spine = 0;            // tokens above depth D-10 owned by the block's first rank
+    unsigned long long spine = 0, spineR = 0; // tokens above depth D-10 owned by the block's first rank (mid / range stream)
+    const uint8_t *CbR = a.codesR ? a.codesR + (int64_t)brick * a.codeStride : nullptr;
     int nsp = 0;
     const uint32_t r0 = (uint32_t)blk << sub;
     const int jmin = r0 ? a.D - (__ffs((int)r0) - 1) : 0;     // first spine depth of rank r0 (<= dl)
@@ -2001,7 +2090,11 @@ k_block_alive(EmitArgs a, int64_t nblk, int sub)     // sub: log2 of the leaves 
     for (int j = 0; j < dl; ++j) {
         const int code = cget(Cb, ((int64_t)1 << j) + (blk >> (dl - j)));
         if (j > 0) val = apply_code(val, code, dmap[j]);
-        if (pathAlive && j >= jmin) { spine |= (unsigned long long)code << (2 * nsp); ++nsp; }
+        if (pathAlive && j >= jmin) {
+            spine |= (unsigned long long)code << (2 * nsp);
+            if (CbR) spineR |= (unsigned long long)cget(CbR, ((int64_t)1 << j) + (blk >> (dl - j))) << (2 * nsp);   // 3 wherever the mid code is
+            ++nsp;
+        }
         if (code == 3 && pathAlive) {
             // first pruned node on the path: it is emitted itself, by the block holding ITS first leaf
             alive = ((blk >> (dl - j)) << (dl - j)) == blk;
@@ -2012,6 +2105,7 @@ k_block_alive(EmitArgs a, int64_t nblk, int sub)     // sub: log2 of the leaves 
     a.blockAlive[o] = (uint8_t)((alive ? 1 : 0) | (pathAlive ? 2 : 0));   // bit1: the depth-(D-10) node itself is live
     a.blockVal[o] = (uint8_t)val;            // scalar of the depth-(D-11) parent (codes applied down to depth dl-1)
     a.blockSpine[o] = spine | ((unsigned long long)nsp << 56);
+    if (CbR) a.blockSpineR[o] = spineR | ((unsigned long long)nsp << 56);
     // tokens this block emits: the upper spine its first rank owns + its own subtree if that is live
     // (k_prune12 left the subtree's count in blockOff[], which k_emit_scan overwrites afterwards)
     a.blockTot[o] = (uint32_t)nsp + (pathAlive ? a.blockOff[o] : 0u);
@@ -2115,6 +2209,7 @@ k_emit4(EmitArgs a)
 // offset blockOff[b].  Also turns the block-local index offsets into stream offsets and fills the index
 // values (the scalar decoded down to depth Ds; codes under a pruned node are all 3, so the walk is the
 // same for live and dead entries).
+template <bool RANGE>        // RANGE: MidRangeTree's second stream -- same offsets and shape, its own staged strings and spine; no index
 __global__ void __launch_bounds__(64)
 k_concat12(EmitArgs a)       // one wave per block string: many small workgroups in flight hide the memory round trips
 {
@@ -2126,7 +2221,7 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
     // round trip 1: the block record, my index entry and the seven codes above it (all independent)
     const int bflags = a.blockAlive[bo];
     const int bval = a.blockVal[bo];
-    const unsigned long long upSpine = a.blockSpine[bo];
+    const unsigned long long upSpine = RANGE ? a.blockSpineR[bo] : a.blockSpine[bo];
     const uint32_t g0 = a.blockOff[bo], tot = a.blockTot[bo];
     const uint32_t s = (blk << 6) + (uint32_t)t;                        // my depth-Ds (= D-6) subtree
     const int64_t io = (int64_t)brick * a.nIdx + s;
@@ -2150,7 +2245,7 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
     const int dl5 = c.distanceMap[D - 5], dl4 = c.distanceMap[D - 4], dl3 = c.distanceMap[D - 3];
     const int nsp = (int)(upSpine >> 56);
     const unsigned long long spine = upSpine & 0x00FFFFFFFFFFFFFFull;
-    {
+    if (!RANGE) {
         int val = bval;                             // scalar of the block root's parent
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
@@ -2180,8 +2275,10 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
     const int nws = (int)((cnt + 15u) >> 4);
     const uint32_t phase = g0 & 15u;
     const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
-    uint32_t *G = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap) + (g0 >> 4);
-    const PeStage stg = pe_stage_of(const_cast<uint8_t *>(a.temp), a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk);
+    uint32_t *G = (uint32_t *)((RANGE ? a.treeR : a.tree) + (int64_t)brick * a.treeCap) + (g0 >> 4);
+    const PeStage stg = RANGE ? pe_stage_of(const_cast<uint8_t *>(a.tempR), a.heapStride, a.rbR, a.ctrlsR[brick].ra, a.ctrlsR[brick].rb,
+                                            a.leafStride, brick, blk)
+                              : pe_stage_of(const_cast<uint8_t *>(a.temp), a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk);
     for (uint32_t i0 = 0; i0 < nwo; i0 += 256) {        // four words per lane and trip: eight loads in flight
         uint32_t lo[4], hi[4];
         int sbv[4];
@@ -2397,7 +2494,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     int pruneFrom = D - 1;
     bs->fineHas.assign((size_t)B, 0);
-    const bool fused = !mr && D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
+    const bool fused = D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
     if (fused) {
         PruneEmitArgs pa;
         pa.D = D; pa.tol = bs->tolerance; pa.maxDepth = bs->maxDepth; pa.ctrls = bs->mid.ctrl;
@@ -2408,7 +2505,10 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         if (!bs->fineIdx && hipMalloc(&bs->fineIdx, (size_t)B * bs->nIdx * 16) != hipSuccess) return -3;
         if (!bs->idxVal3 && hipMalloc(&bs->idxVal3, (size_t)B * bs->nIdx * 8) != hipSuccess) return -3;
         pa.fineIdx = (uint32_t *)bs->fineIdx;
-        hipLaunchKernelGGL(k_prune_emit12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
+        pa.ctrlsR = mr ? bs->rng.ctrl : nullptr; pa.tempR = mr ? bs->rng.temp : nullptr; pa.codesR = mr ? bs->rng.codes : nullptr;
+        pa.rbR = rbR;
+        hipLaunchKernelGGL(k_prune_emit12<false>, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
+        if (mr) hipLaunchKernelGGL(k_prune_emit12<true>, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
         pruneFrom = D - 13;
         bs->fineHas.assign((size_t)B, 1);
     } else if (D >= 12) {
@@ -2439,11 +2539,11 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
     a.blockL1 = bs->blockL1;
-    a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine;
+    a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine; a.blockSpineR = bs->blockSpineR;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.idxVal3 = bs->idxVal3; a.nIdx = bs->nIdx;
     a.chainLut = bs->chainLut;
-    const bool quad = !mr && D >= 12 && bs->K >= 2;
+    const bool quad = (!mr || fused) && D >= 12 && bs->K >= 2;
     const int64_t nblk = cdiv((int64_t)1 << D, fused ? 4096 : (quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK));
     if (quad) hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk, fused ? 12 : 10);   // + token counts
     else hipLaunchKernelGGL(k_emit_count, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
@@ -2451,7 +2551,10 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     dbg_sync(st, "emit_scan");
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-    if (fused) hipLaunchKernelGGL(k_concat12, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
+    if (fused) {
+        hipLaunchKernelGGL(k_concat12<false>, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
+        if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
+    }
     else if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     // statistics records: one per 1024 leaves from k_prune12, one per 256 from k_prune_leaf
