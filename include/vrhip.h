@@ -207,7 +207,12 @@ typedef struct vr_render_params {
     int64_t global_dims[3];
     int64_t vol_origin[3];
     int32_t no_early_exit;   /* 1: ignore the alpha>0.99 exit (reference for the sort-last path)   */
-    int32_t reserved;
+    /* Empty-space skipping (new; the reference only hints at it, isosurface_compressed.frag:23-29): skip_grid_dev = a
+     * grid built by vr_skip_grid_build from THE SAME volume_dev, skip_cell its cell size in voxels; NULL / 0 = off.
+     * A sample whose eight taps are provably all zero (compositor) or provably all on one side of the iso value is not
+     * fetched; the ray still advances sample by sample, so the frame is bit-identical to the one without the grid. */
+    int32_t skip_cell;
+    const uint8_t *skip_grid_dev;
 } vr_render_params;
 
 /* volume_dev: X*Y*Z uint8 (the 3-D texture contents, GL_RED/GL_UNSIGNED_BYTE, GL_LINEAR,
@@ -215,6 +220,14 @@ typedef struct vr_render_params {
  * Pixels not covered by the cube are white (main.cpp:392). */
 vr_status vr_raycast(const uint8_t *volume_dev, const int64_t dims[3], const vr_camera *cam,
                      const vr_render_params *params, float *rgba_dev, void *stream);
+
+/* (min, max) of every skip_cell^3 cell of the volume, widened by the one voxel a trilinear fetch reaches beyond its
+ * base voxel: grid_dev holds 2 bytes per cell, cells x fastest, ceil(dims / skip_cell) cells per axis.  Exact bounds of
+ * the DECODED voxels: MidRangeTree's half-range stream would give bounds of the original data one level above, but the
+ * decoded scalar of an internal node is a prediction with no error bound, so mid +- range at a coarse cut is not a safe
+ * bracket (vr_brickset_decode_range remains available for previews). */
+vr_status vr_skip_grid_build(const uint8_t *volume_dev, const int64_t dims[3], int32_t skip_cell, uint8_t *grid_dev,
+                             void *stream);
 
 /* Sort-last compositing of VR_RENDER_PARTIAL images: front = front OVER back, per pixel
  * (c1 + t1*c2, t1*t2); and the final colour transfer of raycaster.frag:82-85. */

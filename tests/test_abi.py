@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     from volumerenderer_amd import _lib
     assert C.sizeof(_lib.TreeInfo) == 88
     assert C.sizeof(_lib.Camera) == 48
-    assert C.sizeof(_lib.RenderParams) == 32 + 24 + 48 + 8
+    assert C.sizeof(_lib.RenderParams) == 32 + 24 + 48 + 8 + 8
 
 
 def test_status_strings(L):

@@ -15,7 +15,8 @@ def __getattr__(name):  # torch is imported lazily so that `import volumerendere
         from . import codec
         return getattr(codec, name)
     if name in ("VolumeReader", "UnitBrick", "raycast", "default_camera", "default_params", "composite_over",
-                "composite_finish", "assemble_bricks", "disassemble_bricks", "fill_volume_brick_map"):
+                "composite_finish", "assemble_bricks", "disassemble_bricks", "fill_volume_brick_map", "build_skip_grid",
+                "use_skip_grid"):
         from . import render
         return getattr(render, name)
     raise AttributeError(name)

@@ -40,7 +40,7 @@ class RenderParams(C.Structure):
                 ("iso_value", C.c_float), ("max_samples", C.c_int32), ("mode", C.c_int32),
                 ("box_min", C.c_float * 3), ("box_max", C.c_float * 3),
                 ("global_dims", C.c_int64 * 3), ("vol_origin", C.c_int64 * 3),
-                ("no_early_exit", C.c_int32), ("reserved", C.c_int32)]
+                ("no_early_exit", C.c_int32), ("skip_cell", C.c_int32), ("skip_grid_dev", C.c_void_p)]
 
 
 # every symbol include/vrhip.h declares, with its signature
@@ -76,6 +76,7 @@ SIGNATURES = {
     "vr_assemble_bricks": (_I32, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "vr_disassemble_bricks": (_I32, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), _P, _P]),
     "vr_raycast": (_I32, [_P, C.POINTER(_I64), C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
+    "vr_skip_grid_build": (_I32, [_P, C.POINTER(_I64), _I32, _P, _P]),
     "vr_composite_over": (_I32, [_P, _P, _I64, _P]),
     "vr_composite_finish": (_I32, [_P, _P, _I64, _P]),
     "vr_composite_slabs": (_I32, [_P, _I32, _I64, _I64, _I32, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),

@@ -14,6 +14,7 @@ using namespace vr;
 namespace vr {
 int raycast_launch(const uint8_t *, const int64_t dims[3], const vr_camera *, const vr_render_params *, float *, hipStream_t);
 int composite_over_launch(float *, const float *, int64_t, hipStream_t);
+int skip_grid_launch(const uint8_t *, const int64_t dims[3], int, uint8_t *, hipStream_t);
 int composite_finish_launch(const float *, float *, int64_t, hipStream_t);
 int composite_slabs_launch(const float *, int, int64_t, int64_t, int, const vr_camera *, const vr_render_params *, float *, hipStream_t);
 int assemble_launch(bool, const uint8_t *, uint8_t *, int, const int64_t bd[3], const int64_t *, const int64_t grid[3], hipStream_t);
@@ -708,6 +709,14 @@ vr_status vr_raycast(const uint8_t *vol, const int64_t dims[3], const vr_camera 
     if (P->width <= 0 || P->height <= 0 || P->max_samples < 0 || P->mode < 0 || P->mode > 2) return VR_ERR_INVALID;
     if (!device_ok()) return VR_ERR_NO_DEVICE;
     return raycast_launch(vol, dims, cam, P, rgba, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+vr_status vr_skip_grid_build(const uint8_t *vol, const int64_t dims[3], int32_t cell, uint8_t *grid, void *stream)
+{
+    if (!vol || !dims || !grid || cell <= 0 || cell > 64) return VR_ERR_INVALID;
+    for (int k = 0; k < 3; ++k) if (dims[k] <= 0 || dims[k] >= (1ll << 31)) return VR_ERR_INVALID;
+    if (!device_ok()) return VR_ERR_NO_DEVICE;
+    return skip_grid_launch(vol, dims, cell, grid, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
 }
 
 vr_status vr_composite_over(float *front, const float *back, int64_t n, void *stream)

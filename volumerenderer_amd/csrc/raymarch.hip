@@ -67,8 +67,46 @@ __device__ __forceinline__ bool inside(float x, float y, float z)
     return !(d < 3.0f);
 }
 
+// ---- empty-space skipping (new; isosurface_compressed.frag:23-29 only declares the intent) ---------------------
+// grid[2 * cell] = min, [2 * cell + 1] = max over the voxels [c * S, c * S + S] per axis (S = cell size; the + 1 is the
+// second tap of a trilinear fetch whose base voxel lies in the cell), clamped to the volume.  A fetch at texture position
+// p has its base voxel at floor(p * G - 0.5), clamped like the taps themselves, so its eight taps lie inside that cell's
+// bounds.
+struct SkipGrid { const uint8_t *g; int S, nx, ny, nz; };
+
+__global__ void __launch_bounds__(256)
+k_skip_grid(const uint8_t *__restrict__ vol, int X, int Y, int Z, int S, int nx, int ny, int nz, uint8_t *__restrict__ grid)
+{
+    // one wave per cell: lanes stride over its (S+1)^3 voxels, DPP-free shuffle reduction
+    const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (cell >= (int64_t)nx * ny * nz) return;
+    const int cx = (int)(cell % nx), cy = (int)((cell / nx) % ny), cz = (int)(cell / ((int64_t)nx * ny));
+    const int x0 = cx * S, y0 = cy * S, z0 = cz * S;
+    const int ex = min(S + 1, X - x0), ey = min(S + 1, Y - y0), ez = min(S + 1, Z - z0);
+    int mn = 255, mx = 0;
+    const int n = ex * ey * ez;
+    for (int i = lane; i < n; i += 64) {
+        const int dx = i % ex, dy = (i / ex) % ey, dz = i / (ex * ey);
+        const int v = vol[(int64_t)(x0 + dx) + (int64_t)X * ((y0 + dy) + (int64_t)Y * (z0 + dz))];
+        mn = min(mn, v); mx = max(mx, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o)); }
+    if (lane == 0) { grid[2 * cell] = (uint8_t)mn; grid[2 * cell + 1] = (uint8_t)mx; }
+}
+
+// bounds of the eight taps of tex3d(t, px, py, pz): (min | max << 8)
+__device__ __forceinline__ uint32_t skip_bounds(const SkipGrid &sg, const Tex &t, float px, float py, float pz)
+{
+    const int x0 = clampi((int)floorf(px * (float)t.GX - 0.5f), 0, t.GX - 1), y0 = clampi((int)floorf(py * (float)t.GY - 0.5f), 0, t.GY - 1),
+              z0 = clampi((int)floorf(pz * (float)t.GZ - 0.5f), 0, t.GZ - 1);
+    const int64_t c = (x0 / sg.S) + (int64_t)sg.nx * ((y0 / sg.S) + (int64_t)sg.ny * (z0 / sg.S));
+    return *(const uint16_t *)(sg.g + 2 * c);
+}
+
 struct RayArgs {
     Tex t;
+    SkipGrid sg;
     vr_camera cam;
     vr_render_params P;
     float f[3], s[3], u[3];
@@ -121,6 +159,8 @@ k_raycast(RayArgs a)
         for (int i = 0; i < ns; ++i) {
             pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
             if (!inside(pos[0], pos[1], pos[2])) break;
+            // all eight taps zero: the sample is exactly 0 and the three updates below are exact no-ops
+            if (a.sg.g && (skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]) >> 8) == 0u) continue;
             float smp = tex3d(a.t, pos[0], pos[1], pos[2]);
             float pa = smp - (smp * A);          // raycaster.frag:69
             rgb = pa * smp + rgb;                // :70
@@ -148,6 +188,14 @@ k_raycast(RayArgs a)
         for (int i = 0; i < ns; ++i) {
             pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
             if (!inside(pos[0], pos[1], pos[2])) break;
+            if (a.sg.g) {
+                // the test below needs s1 < iso <= s2.  Interpolation in float can leave the taps' range by rounding only,
+                // so a whole grey level of margin decides safely: every tap of s1 above iso, or every tap of s2 below it
+                const uint32_t b1 = skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]);
+                if ((float)((int)(b1 & 255u) - 1) * (1.0f / 255.0f) >= iso) continue;
+                const uint32_t b2 = skip_bounds(a.sg, a.t, pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]);
+                if ((float)((int)(b2 >> 8) + 1) * (1.0f / 255.0f) < iso) continue;
+            }
             float s1 = tex3d(a.t, pos[0], pos[1], pos[2]);
             float s2 = tex3d(a.t, pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]);
             if ((s1 - iso) < 0.0f && (s2 - iso) >= 0.0f) {                     // :126
@@ -302,6 +350,12 @@ int raycast_launch(const uint8_t *vol, const int64_t dims[3], const vr_camera *c
     a.t.ox = (int)P->vol_origin[0]; a.t.oy = (int)P->vol_origin[1]; a.t.oz = (int)P->vol_origin[2];
     a.cam = *cam;
     a.P = *P;
+    a.sg.g = nullptr; a.sg.S = 1; a.sg.nx = a.sg.ny = a.sg.nz = 0;
+    // the grid describes volume_dev as a whole: only used where the local volume IS the texture (single-GPU path)
+    if (P->skip_grid_dev && P->skip_cell > 0 && a.t.GX == a.t.X && a.t.GY == a.t.Y && a.t.GZ == a.t.Z && a.t.ox == 0 && a.t.oy == 0 && a.t.oz == 0) {
+        a.sg.g = P->skip_grid_dev; a.sg.S = P->skip_cell;
+        a.sg.nx = (a.t.X + a.sg.S - 1) / a.sg.S; a.sg.ny = (a.t.Y + a.sg.S - 1) / a.sg.S; a.sg.nz = (a.t.Z + a.sg.S - 1) / a.sg.S;
+    }
     // glm::lookAt basis and glm::perspectiveFov half-angle tangents (main.cpp:396-397)
     for (int k = 0; k < 3; ++k) a.f[k] = cam->front[k];
     hnorm3(a.f);
@@ -315,6 +369,15 @@ int raycast_launch(const uint8_t *vol, const int64_t dims[3], const vr_camera *c
     dim3 grid((P->width + 7) / 8, (P->height + 7) / 8);
     hipLaunchKernelGGL(k_raycast, grid, dim3(64), 0, st, a);
     return launch_status("raymarch");
+}
+
+int skip_grid_launch(const uint8_t *vol, const int64_t dims[3], int S, uint8_t *grid, hipStream_t st)
+{
+    const int nx = (int)((dims[0] + S - 1) / S), ny = (int)((dims[1] + S - 1) / S), nz = (int)((dims[2] + S - 1) / S);
+    const int64_t cells = (int64_t)nx * ny * nz;
+    hipLaunchKernelGGL(k_skip_grid, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, st, vol, (int)dims[0], (int)dims[1], (int)dims[2], S,
+                       nx, ny, nz, grid);
+    return launch_status("skip_grid");
 }
 
 int composite_slabs_launch(const float *partials, int nslabs, int64_t npix, int64_t first, int axis, const vr_camera *cam,

@@ -39,7 +39,30 @@ def default_params(width=1600, height=1200, brick_dims=(256, 256, 128), mode=_li
     P.global_dims[:] = (0, 0, 0)
     P.vol_origin[:] = (0, 0, 0)
     P.no_early_exit = 0
+    P.skip_cell = 0
+    P.skip_grid_dev = None
     return P
+
+
+def build_skip_grid(volume, dims, cell=8, out=None, stream=None):
+    """(min, max) per cell^3 voxels (+1 voxel reach of a trilinear fetch) of a device volume: 2 bytes per cell.
+    Attach to render params with use_skip_grid(); the frame stays bit-identical, the marcher just does not fetch
+    samples the grid proves irrelevant."""
+    v = _as_dev_u8(volume)
+    d = (C.c_int64 * 3)(*[int(q) for q in dims])
+    n = [(int(q) + cell - 1) // cell for q in dims]
+    if out is None:
+        out = torch.empty(2 * n[0] * n[1] * n[2], dtype=torch.uint8, device="cuda")
+    check(_lib.lib().vr_skip_grid_build(C.c_void_p(v.data_ptr()), d, int(cell), C.c_void_p(out.data_ptr()), _stream_ptr(stream)),
+          "vr_skip_grid_build")
+    return out
+
+
+def use_skip_grid(params, grid, cell=8):
+    params.skip_cell = int(cell) if grid is not None else 0
+    params.skip_grid_dev = grid.data_ptr() if grid is not None else None
+    params._keep_grid = grid
+    return params
 
 
 def raycast(volume, dims, cam, params, out=None, stream=None):
