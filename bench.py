@@ -232,6 +232,68 @@ def cpu_baseline(vox4, B, V, tolerance, max_epochs, seconds):
                           "sample": "%d bricks, one oracle tree per thread at a time, %.1f s wall" % (host_n, tall)}}
 
 
+def config5_leg(torch, vr, vox4, gdims, bdims, grid, args, timesteps=4, frames_per_stage=4):
+    """BASELINE config 5 at full size: `timesteps` volumes (different seeds) stream from pinned host memory through a
+    MidRangeTree set (both 2-bit streams = the 4-bit packing): upload of t+1 beside the build / decodes / frames of t;
+    every timestep is decoded at cuts D-6 (one value per 4x4x4 block), D (no grown branches) and maxTreeDepth (levelCut)
+    with the half-range stream decoded at the first cut, 1080p frames on a 1-degree-per-frame orbit after each stage.
+    Also times the MidRangeTree build + decode alone (the 4-bit path's throughput)."""
+    from volumerenderer_amd.pipeline import TimestepStreamer
+    B = vox4.shape[0]
+    V = bdims[0] * bdims[1] * bdims[2]
+    st = TimestepStreamer(B, bdims, args.tolerance, args.max_epochs, variant=2)
+    D = st.bs.build(vox4.reshape(-1)).info(0)["orig_tree_depth"]
+    out = st.out[0]
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(3):                       # MidRangeTree build + levelCut, serial (4-bit stream pair)
+        st.bs.build(vox4.reshape(-1)); st.bs.decode(out)
+        torch.cuda.synchronize()
+        tm = st.bs.last_timings()
+        ms.append(tm["BUILD"] + tm["COMPRESS"] + tm["PRUNE"] + tm["CONVERT"] + tm["DECODE"])
+    mr_ms = min(ms)
+    host = [torch.empty(B * V, dtype=torch.uint8, pin_memory=True) for _ in range(timesteps)]
+    host[0].copy_(vox4.reshape(-1))
+    for t in range(1, timesteps):
+        host[t].copy_(make_volume_gpu(torch, gdims, bdims, seed=12345 + 77 * t).reshape(-1))
+    torch.cuda.synchronize()
+    ijk_all = np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])] for b in range(B)], np.int64)
+    whole = torch.empty(B * V, dtype=torch.uint8, device="cuda")
+    rng = torch.empty(B * V, dtype=torch.uint8, device="cuda")
+    img = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    cam, P = vr.default_camera(), vr.default_params(1920, 1080, (256, 256, 128))
+    cuts = [D - 6, D, D + 7]
+    theta = [0.0]
+    nframes = [0]
+
+    def on_stage(t, k, cut, vol, stream):
+        if k == 0:
+            st.bs.decode_range(rng, cut_depth=cut, stream=stream)       # [mid - range, mid + range] preview bounds
+        vr.assemble_bricks(vol, bdims, ijk_all, grid, out=whole, stream=stream)
+        for _ in range(frames_per_stage):
+            th = math.radians(theta[0]); theta[0] += 1.0
+            cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
+            cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
+            vr.raycast(whole, gdims, cam, P, img, stream=stream)
+            nframes[0] += 1
+
+    st.run_progressive(host[:1], cuts, on_stage)          # warm-up (first touch of every buffer)
+    nframes[0] = 0
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    ev = st.run_progressive(host, cuts, on_stage)
+    wall = time.perf_counter() - w0
+    first = [e["uploaded"].elapsed_time(e["stages"][0]) for e in ev]
+    refine = [e["stages"][0].elapsed_time(e["stages"][-1]) for e in ev]
+    build = [e["uploaded"].elapsed_time(e["built"]) for e in ev]
+    return {"timesteps": timesteps, "bricks_per_timestep": B, "variant": "MidRangeTree (2 x 2-bit streams = 4-bit packing)",
+            "cuts": cuts, "frames": nframes[0], "wall_s": round(wall, 3), "fps_1080p_incl_build_and_decodes": round(nframes[0] / wall, 1),
+            "timesteps_per_s": round(timesteps / wall, 2),
+            "upload_to_first_frame_ms": round(sum(first) / len(first), 2), "first_to_full_refine_ms": round(sum(refine) / len(refine), 2),
+            "build_ms_in_stream": round(sum(build) / len(build), 2),
+            "midrange_build_plus_decode_ms": round(mr_ms, 2), "midrange_Mvoxels_per_s": round(B * V / mr_ms / 1e3, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +308,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the MidRangeTree / config-5 streaming leg")
     ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
                     help="bricksets in flight.  3 (default, ~65 GB each of the 288 GB): two build streams and a decode "
                          "stream -- the levelCut of step k and the build of step k+1 run beside the build of step k+2 "
@@ -424,25 +487,41 @@ def main():
            "roofline": roofline}
 
     if not args.no_render and not args.bricks and rank == 0:
-        # 1080p ray-cast of the decoded volume (raycaster.frag) on a camera orbit, fps
-        vol = vr.assemble_bricks(out, bdims, np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])]
-                                                        for b in range(B)], np.int64), grid)
+        # 1080p frames of the decoded volume on a camera orbit: raycaster.frag and isosurface.frag, each also with the
+        # empty-space skip grid (bit-identical frames, tests/test_gpu_render_pins.py)
+        ijk_all = np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])] for b in range(B)], np.int64)
+        vol = vr.assemble_bricks(out, bdims, ijk_all, grid)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        sgrid = vr.build_skip_grid(vol, gdims, 8)
+        torch.cuda.synchronize()
+        res["skip_grid_build_ms"] = round((time.perf_counter() - g0) * 1e3, 2)
         cam = vr.default_camera()
-        P = vr.default_params(1920, 1080, (256, 256, 128))
         img = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
         frames = 36
-        for warm in (True, False):
-            torch.cuda.synchronize()
-            r0 = time.perf_counter()
-            for f in range(frames):
-                th = math.radians(f * 10.0)
-                cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
-                cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
-                vr.raycast(vol, gdims, cam, P, img)
-            torch.cuda.synchronize()
-            fps = frames / (time.perf_counter() - r0)
-        res["raycast_1080p_fps"] = round(fps, 1)
-        del vol
+
+        def orbit_fps(P):
+            fps = 0.0
+            for warm in (True, False):
+                torch.cuda.synchronize()
+                r0 = time.perf_counter()
+                for f in range(frames):
+                    th = math.radians(f * 10.0)
+                    cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
+                    cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
+                    vr.raycast(vol, gdims, cam, P, img)
+                torch.cuda.synchronize()
+                fps = frames / (time.perf_counter() - r0)
+            return round(fps, 1)
+
+        P = vr.default_params(1920, 1080, (256, 256, 128))
+        res["raycast_1080p_fps"] = orbit_fps(P)
+        res["raycast_1080p_fps_skip_grid"] = orbit_fps(vr.use_skip_grid(vr.default_params(1920, 1080, (256, 256, 128)), sgrid, 8))
+        Pi = vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_ISOSURFACE, 40.0 / 255.0)     # main.cpp:52,334
+        res["isosurface_1080p_fps"] = orbit_fps(Pi)
+        res["isosurface_1080p_fps_skip_grid"] = orbit_fps(vr.use_skip_grid(
+            vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_ISOSURFACE, 40.0 / 255.0), sgrid, 8))
+        del vol, sgrid
 
     if world > 1 and args.composite and not args.bricks:
         try:
@@ -480,6 +559,14 @@ def main():
         except Exception as ex:   # the composited frame is an extra: never let it take the headline metric down
             res["composited_1080p_error"] = repr(ex)[:200]
 
+    if rank == 0 and world == 1 and not args.no_stream and not args.bricks and args.kind == "rm_volume":
+        del sets, bs
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        try:
+            res["config5"] = config5_leg(torch, vr, vox4, gdims, bdims, grid, args)
+        except Exception as ex:       # an extra: never lets the headline line go missing
+            res["config5"] = {"error": repr(ex)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(vox4, B, V, args.tolerance, args.max_epochs, args.cpu_seconds)
     if rank == 0:

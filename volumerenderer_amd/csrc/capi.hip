@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <new>
 
 using namespace vr;
@@ -682,13 +684,26 @@ static vr_status assemble_common(bool toVolume, const uint8_t *src, int32_t nb, 
         for (int k = 0; k < 3; ++k)
             if (ijk[3 * b + k] < 0 || ijk[3 * b + k] >= grid[k]) return VR_ERR_INVALID;
     if (!device_ok()) return VR_ERR_NO_DEVICE;
+    // the brick map lives on the device: uploaded once per distinct map and kept (a streaming loop calls this every
+    // frame with the same map; allocating, copying and synchronising each time would serialise the pipeline)
+    static std::mutex mu;
+    static std::map<std::vector<int64_t>, int64_t *> cache;
     int64_t *d = nullptr;
-    HIPCHK(hipMalloc(&d, (size_t)nb * 3 * sizeof(int64_t)));
-    hipError_t e = hipMemcpyAsync(d, ijk, (size_t)nb * 3 * sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream);
-    int rc = e == hipSuccess ? assemble_launch(toVolume, src, dst, nb, bd, d, grid, (hipStream_t)stream) : -1;
-    hipStreamSynchronize((hipStream_t)stream);
-    hipFree(d);
-    return rc == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<int64_t> key(ijk, ijk + (size_t)nb * 3);
+        int dev = 0;
+        hipGetDevice(&dev);
+        key.push_back(dev);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            if (cache.size() >= 64) { for (auto &kv : cache) hipFree(kv.second); cache.clear(); }
+            HIPCHK(hipMalloc(&d, (size_t)nb * 3 * sizeof(int64_t)));
+            if (hipMemcpy(d, ijk, (size_t)nb * 3 * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return VR_ERR_NO_DEVICE; }
+            cache.emplace(std::move(key), d);
+        } else d = it->second;
+    }
+    return assemble_launch(toVolume, src, dst, nb, bd, d, grid, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
 }
 
 vr_status vr_assemble_bricks(const uint8_t *bricks, int32_t nb, const int64_t bd[3], const int64_t *ijk,
