@@ -36,6 +36,11 @@ def test_full_volume_properties(oracle, monkeypatch):
     monkeypatch.delenv("VRHIP_DECODE_WALK")
     assert torch.equal(fine, walk)
     del walk
+    monkeypatch.setenv("VRHIP_DECODE_FINE_V1", "1")       # ... and so does the round-1 fine kernel (k_decode_quad is the default)
+    v1 = bs.decode()
+    monkeypatch.delenv("VRHIP_DECODE_FINE_V1")
+    assert torch.equal(fine, v1)
+    del v1
     again = bs.decode()
     assert torch.equal(fine, again)
     del again
@@ -69,3 +74,52 @@ def test_full_volume_properties(oracle, monkeypatch):
         ref = oracle.OracleTree(host.copy(), tolerance=1, max_epochs=2).build()
         assert ref.numActiveNodes == infos[b]["num_active_nodes"] and np.array_equal(ref.tree, bs.tree(b))
         assert np.array_equal(ref.levelCut().reshape(-1), fine[b * V:(b + 1) * V].cpu().numpy())
+
+
+def test_config3_eight_256_cubed_bricks(oracle):
+    """BASELINE config 3 at its real size: 8 bricks of 256^3 (a 512^3 volume), the error-tolerance sweep and the
+    iso-surface shader.  On all 134 M voxels: decoded max error = the encoder's own statistic wherever no epoch was
+    reverted, larger tolerance never costs more tokens, decoding is idempotent, 1080p
+    iso-surface frames are finite and bit-identical with the skip grid; the oracle runs on one brick per tolerance."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    import volumerenderer_amd as vr
+    n, B = 256, 8
+    vols = np.stack([oracle.gen_sphere(n, 7 if b % 2 else 3, seed=4242 + b) for b in range(B)])
+    dvox = torch.from_numpy(vols).cuda().reshape(-1)
+    bmap = vr.fill_volume_brick_map(2, 2, 2)
+    ijk = np.array([bmap[b] for b in range(B)], np.int64)
+    prev_tokens = None
+    for tol in (0, 1, 2, 4, 6, 12):
+        bs = vr.BrickSet(B, (n, n, n), tol, 2)
+        bs.build(dvox)
+        dec = bs.decode()
+        assert torch.equal(dec, bs.decode())
+        infos = [bs.info(b) for b in range(B)]
+        err = (dec.view(B, -1).to(torch.int16) - dvox.view(B, -1).to(torch.int16)).abs().amax(dim=1).cpu().numpy()
+        mx, mean = vr.measure_error(dec, dvox)
+        assert mx == int(err.max()) and mean >= 0
+        for b in range(B):
+            if infos[b]["num_reverts"] == 0:
+                assert err[b] == infos[b]["max_error_after"], (tol, b)
+            assert infos[b]["zero_run_rewrites"] == 0
+        tokens = sum(i["num_active_nodes"] for i in infos)
+        assert prev_tokens is None or tokens <= prev_tokens, tol
+        prev_tokens = tokens
+        if tol in (1, 6):
+            b = 3
+            ref = oracle.OracleTree(vols[b].copy(), tolerance=tol, max_epochs=2).build()
+            assert np.array_equal(ref.tree, bs.tree(b)) and list(ref.distanceMap) == list(bs.distance_map(b))
+            assert np.array_equal(ref.levelCut().reshape(-1), dec.view(B, -1)[b].cpu().numpy())
+        if tol in (1, 12):
+            whole = vr.assemble_bricks(dec, (n, n, n), ijk, (2, 2, 2))
+            grid = vr.build_skip_grid(whole, (2 * n,) * 3, 8)
+            cam = vr.default_camera()
+            for iso in (40 / 255.0, 80 / 255.0, 120 / 255.0):
+                P = vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_ISOSURFACE, iso)
+                a = vr.raycast(whole, (2 * n,) * 3, cam, P)
+                b_ = vr.raycast(whole, (2 * n,) * 3, cam, vr.use_skip_grid(vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_ISOSURFACE, iso), grid, 8))
+                assert torch.isfinite(a).all() and torch.equal(a, b_)
+                assert (a[..., 0] < 1).any()
+        del bs, dec
