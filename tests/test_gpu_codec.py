@@ -613,3 +613,24 @@ def test_midrange_on_the_fused_kernels(vr, oracle, shape, tol, ep):
         for cut in (None, D, D - 6, 4):
             got = bs.decode_range(cut_depth=-1 if cut is None else cut).cpu().numpy().reshape(shape)
             assert np.array_equal(got, ref.levelCutRange(cut)), cut
+
+
+@pytest.mark.parametrize("shape", [(40, 16, 24), (16, 32, 128), (96, 64, 48)])
+def test_64_bit_token_offsets_small(vr, oracle, shape, monkeypatch):
+    """Trees deeper than 28 levels (the reference's own 2048 x 2048 x 768 volume is 31 deep, main.cpp:242-251) can hold
+    more than 2^32 tokens: the emitter then scans in 64 bits and the decode index is kept relative to its 4096-leaf
+    block.  VRHIP_FORCE_IDX64 takes small bricks through exactly that code, where the oracle can check every byte."""
+    monkeypatch.setenv("VRHIP_FORCE_IDX64", "1")
+    rng = np.random.default_rng(shape[2])
+    for vol, tol, ep in ((rng.integers(0, 256, shape, dtype=np.uint8), 1, 2), (rm_like(shape), 1, 2), (_mixed_volume(rng, shape), 4, 5)):
+        ref, bs = check_case(vr, oracle, vol, tol, ep)
+        D = ref.origTreeDepth
+        for cut in (D - 7, D - 1, D + 3):
+            assert np.array_equal(bs.decode(cut_depth=cut).cpu().numpy().reshape(shape), ref.levelCutProgressive(cut)), cut
+    z, y, x = shape
+    vol = rm_like(shape, 8)
+    ref = oracle.OracleTree(vol.copy(), tolerance=1, max_epochs=2, guarded=True, midrange=True).build()
+    ms = vr.BrickSet(1, (x, y, z), 1, 2, 2).build(vol.copy())
+    assert np.array_equal(ms.tree(0), ref.tree) and np.array_equal(ms.tree_range(0), ref.tree_range)
+    assert np.array_equal(ms.decode().cpu().numpy().reshape(shape), ref.levelCut())
+    assert np.array_equal(ms.decode_range().cpu().numpy().reshape(shape), ref.levelCutRange(None))

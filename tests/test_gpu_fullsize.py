@@ -2,6 +2,7 @@
 properties: the oracle cannot walk 8 G voxels in a test, so what is checked on all of them is what must hold at any
 size -- both decode kernels agree, decoding is idempotent, constant bricks come back exactly, the batch is
 independent of its neighbours -- and the oracle is run on a sample of bricks taken from the batch."""
+import math
 import os
 import sys
 
@@ -123,3 +124,65 @@ def test_config3_eight_256_cubed_bricks(oracle):
                 assert torch.isfinite(a).all() and torch.equal(a, b_)
                 assert (a[..., 0] < 1).any()
         del bs, dec
+
+
+def _big_single_tree(oracle, gdims, tmp_path, oracle_build):
+    """One VolumeKdtree over a whole assembled volume, as main.cpp:242-281 does: LoadBricksToTexture -> build ->
+    save -> levelCut.  The oracle (the reference's algorithm on the host) reads the saved file and walks the stream
+    the GPU wrote; with oracle_build it also builds its own tree from the voxels (minutes at these sizes)."""
+    import torch
+    import __graft_entry__ as g
+    g.build()
+    import volumerenderer_amd as vr
+    sys.path.insert(0, ROOT)
+    from bench import make_volume_gpu
+    bdims = (256, 256, 64)
+    grid = tuple(gdims[k] // bdims[k] for k in range(3))
+    vox4 = make_volume_gpu(torch, gdims, bdims, seed=777)
+    B = vox4.shape[0]
+    bmap = vr.fill_volume_brick_map(*grid)
+    ijk = np.array([bmap[b] for b in range(B)], np.int64)
+    vol = vr.assemble_bricks(vox4.reshape(-1), bdims, ijk, grid)                  # VolumeReader.h:151-223
+    del vox4
+    t = vr.BrickSet(1, gdims, 1, 2)
+    t.build(vol)
+    info = t.info(0)
+    nX, nY, nZ = (int(math.floor(math.log2(q))) for q in gdims)
+    assert info["orig_tree_depth"] == nX + nY + nZ and info["max_tree_depth"] == nX + nY + nZ + 7      # R.cpp:26-30
+    assert info["zero_run_rewrites"] == 0 and info["tree_bytes"] == (info["num_active_nodes"] + 3) // 4
+    dec = t.decode()
+    assert torch.equal(dec, t.decode())                                          # idempotent
+    # the voxels a leaf reads come back within the encoder's own error statistic (no epoch reverted -> decode ==
+    # the encoder's reconstruction); the others are whatever their leaf's box was filled with, or the zero levelCut leaves
+    err = (dec.to(torch.int16) - vol.to(torch.int16)).abs()
+    if info["num_reverts"] == 0:
+        assert int((err <= info["max_error_after"]).sum()) >= (1 << info["orig_tree_depth"]) // 2
+    p = str(tmp_path / "big.bin")
+    t.save(p)
+    assert os.path.getsize(p) == 88 + info["max_tree_depth"] + 1 + info["tree_bytes"]             # R.cpp:535-544
+    ref = oracle.OracleTree.open(p)
+    assert ref.numActiveNodes == info["num_active_nodes"]
+    want = ref.levelCut()
+    assert np.array_equal(want.reshape(-1), dec.cpu().numpy())
+    if oracle_build:
+        own = oracle.OracleTree(vol.cpu().numpy().reshape(gdims[2], gdims[1], gdims[0]), tolerance=1, max_epochs=2).build()
+        assert list(own.distanceMap) == list(t.distance_map(0)) and own.numActiveNodes == info["num_active_nodes"]
+        assert oracle.fnv1a64(own.tree) == oracle.fnv1a64(t.tree(0))
+    os.remove(p)
+    return info
+
+
+@pytest.mark.skipif(os.environ.get("VRHIP_BIG_TESTS") != "1", reason="minutes of host time: VRHIP_BIG_TESTS=1")
+def test_tree_29_levels_deep_against_the_oracle(oracle, tmp_path):
+    """2048 x 1024 x 192 (D = 11 + 10 + 7 = 28 -> with 2048 x 2048 x 192 it is 29): the 64-bit emitter and the
+    table-driven geometry at a size the oracle can still build itself."""
+    _big_single_tree(oracle, (2048, 2048, 192), tmp_path, oracle_build=True)
+
+
+@pytest.mark.skipif(os.environ.get("VRHIP_BIG_TESTS") != "1", reason="minutes of host time: VRHIP_BIG_TESTS=1")
+def test_the_references_own_volume_2048x2048x768(oracle, tmp_path):
+    """main.cpp:242-281 at its real size: 384 bricks assembled into 2048 x 2048 x 768, ONE tree (origTreeDepth 31,
+    2^31 leaves for 3.2 G voxels), save, levelCut.  The oracle walks the stream the GPU wrote (levelCut on the saved file)
+    and must produce the same 3.2 G voxels."""
+    info = _big_single_tree(oracle, (2048, 2048, 768), tmp_path, oracle_build=False)
+    assert info["orig_tree_depth"] == 31

@@ -38,6 +38,8 @@ struct BrickSet {
     unsigned long long *blockSpine = nullptr, *blockSpineR = nullptr; // B * nEmitBlk (R: MidRangeTree's range stream)
     uint32_t *chainLut = nullptr;   // 256: grown branch of a leaf by its initial error (k_chain_lut)
     uint32_t *blockTot = nullptr, *blockOff = nullptr; // B * nEmitBlk
+    bool idx64 = false;            // more than 2^32 tokens possible (origTreeDepth > 28; VRHIP_FORCE_IDX64=1 for tests): 64-bit scan,
+    unsigned long long *blockOff64 = nullptr, *idxBase = nullptr;   // block-relative index entries + per-block bases (B * nEmitBlk each)
     int64_t nEmitBlk = 0;
     uint32_t *idxOff = nullptr; // B * nIdx  token offset of each depth-Ds subtree root (VR_IDX_DEAD: inside a pruned region)
     uint8_t *idxVal = nullptr;  // B * nIdx  decoded scalar of that root (or of the pruned ancestor)

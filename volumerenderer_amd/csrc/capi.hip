@@ -134,7 +134,7 @@ static void free_encoder_buffers(BrickSet &b)
     }
     for (int i = 0; i < 2; ++i) { drop(b.mmMin[i]); drop(b.mmMax[i]); }
     drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine); drop(b.blockSpineR);
-    drop(b.chainLut); drop(b.blockTot); drop(b.blockOff);
+    drop(b.chainLut); drop(b.blockTot); drop(b.blockOff); drop(b.blockOff64); drop(b.idxBase);
     b.encoderReady = false;
 }
 
@@ -169,6 +169,10 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.chainLut, 260 * sizeof(uint32_t)));   // 256 entries + [256]: entries that would need the zero-run rewrite
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
+    if (b.idx64) {
+        HIPCHK(hipMalloc(&b.blockOff64, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&b.idxBase, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
+    }
     return VR_OK;
 }
 
@@ -208,8 +212,8 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     // power-of-two extents up to 1024 per axis take the tiled kernels; anything else (the reference accepts any
     // extents, R.cpp:26-36,151-162) goes through the general-extent tables.  One tree holds at most 2^28 leaves and
     // 2^31 voxels here (32-bit ranks, voxel indices and token offsets).
-    const bool general = !pow2(dims[0]) || !pow2(dims[1]) || !pow2(dims[2]) || dims[0] > 1024 || dims[1] > 1024 || dims[2] > 1024;
-    if (dims[0] > (1ll << 20) || dims[1] > (1ll << 20) || dims[2] > (1ll << 20) || dims[0] * dims[1] * dims[2] >= (1ll << 31))
+    bool general = !pow2(dims[0]) || !pow2(dims[1]) || !pow2(dims[2]) || dims[0] > 1024 || dims[1] > 1024 || dims[2] > 1024;
+    if (dims[0] > (1ll << 20) || dims[1] > (1ll << 20) || dims[2] > (1ll << 20) || dims[0] * dims[1] * dims[2] >= (1ll << 32))
         return VR_ERR_UNSUPPORTED;
     if (!device_ok()) return VR_ERR_NO_DEVICE;
     vr_brickset *h = new (std::nothrow) vr_brickset();
@@ -218,7 +222,12 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     b.B = num_bricks;
     make_geom(b.g, dims);
     b.D = b.g.D;
-    if (b.D > 28) { delete h; return VR_ERR_UNSUPPORTED; }
+    if (b.D > 31) { delete h; return VR_ERR_UNSUPPORTED; }
+    // deeper than 28 (the reference's own 2048x2048x768 tree is 31 deep, main.cpp:242-251): a stream can pass 2^32
+    // tokens, so the emitter scans in 64 bits and the decode index goes block-relative; table-driven geometry only
+    b.idx64 = b.D > 28 || (getenv("VRHIP_FORCE_IDX64") && b.D >= 12);
+    if (b.idx64) general = true;       // the tiled decoders read absolute 32-bit index entries
+    if (b.idx64 && num_bricks != 1 && b.D > 28) { delete h; return VR_ERR_UNSUPPORTED; }
     b.generalGeom = general;
     b.maxDepth = b.D + VR_CHAIN_LEVELS;
     b.tolerance = tolerance; b.maxEpochs = max_epochs; b.variant = variant;
@@ -469,6 +478,7 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     if (!h || !tree || !dmap || brick < 0 || brick >= h->s.B) return VR_ERR_INVALID;
     BrickSet &b = h->s;
     if (map_len < b.maxDepth + 1 || num_active <= 0) return VR_ERR_INVALID;
+    if (num_active >= (1ll << 32)) return VR_ERR_UNSUPPORTED;      // the host-side index of a foreign stream is 32-bit
     const int64_t need = (num_active + 3) / 4;
     if (tree_bytes < need || need > b.treeCap) return VR_ERR_FORMAT;
     std::vector<uint32_t> offs;
@@ -501,6 +511,10 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     b.built = true;
     b.hostCtrlValid = true;
     b.foreign = true;
+    if (b.idx64) {      // absolute 32-bit offsets from the host parse: bases are zero
+        if (!b.idxBase) { b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256; HIPCHK(hipMalloc(&b.idxBase, (size_t)b.B * b.nEmitBlk * sizeof(unsigned long long))); }
+        HIPCHK(hipMemset(b.idxBase, 0, (size_t)b.B * b.nEmitBlk * sizeof(unsigned long long)));
+    }
     if ((int)b.fineHas.size() != b.B) b.fineHas.assign((size_t)b.B, 0);
     b.fineHas[(size_t)brick] = 0;
     if (!fine.empty()) {

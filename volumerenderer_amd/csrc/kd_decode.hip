@@ -155,6 +155,8 @@ void make_lut(const Geom &g, int K, std::vector<uint32_t> &lut)
 struct DecodeArgs {
     const uint8_t *tree;
     int64_t treeCap;
+    const unsigned long long *idxBase;   // 64-bit trees: stream offset of every 4096-leaf block (idxOff is then block-relative)
+    int64_t nBase;
     const uint32_t *idxOff;
     const uint8_t *idxVal;
     int64_t nIdx;
@@ -197,7 +199,8 @@ k_decode_lane(DecodeArgs a)
     };
     if (off == VR_IDX_DEAD) { fill(0, 1u << K, val0); return; }
     const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
-    uint32_t pos = off;
+    unsigned long long pos = off;
+    if (a.idxBase) pos += a.idxBase[(int64_t)brick * a.nBase + (s >> 6)];
     int vals[16];
     int j = 0;
     uint32_t path = 0;
@@ -1139,6 +1142,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         if (!bs->rankVals && hipMalloc(&bs->rankVals, (size_t)bs->B * bs->leafStride * 2) != hipSuccess) return -3;
         DecodeArgs a;
         a.tree = sm.tree; a.treeCap = bs->treeCap;
+        a.idxBase = bs->idx64 ? bs->idxBase : nullptr; a.nBase = bs->nEmitBlk;
         a.idxOff = bs->idxOff; a.idxVal = idxVals; a.nIdx = bs->nIdx;
         a.ctrls = sm.ctrl; a.lut = nullptr; a.out = bs->rankVals; a.g = bs->g;
         a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;
@@ -1185,6 +1189,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
     } else {
         DecodeArgs a;
         a.tree = sm.tree; a.treeCap = bs->treeCap;
+        a.idxBase = nullptr; a.nBase = 0;
         a.idxOff = bs->idxOff; a.idxVal = idxVals; a.nIdx = bs->nIdx;
         a.ctrls = sm.ctrl; a.lut = bs->lut; a.out = out; a.g = bs->g;
         a.D = bs->D; a.K = bs->K; a.Ds = bs->Ds;

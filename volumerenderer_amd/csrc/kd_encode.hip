@@ -1323,6 +1323,8 @@ struct EmitArgs {
     int64_t heapStride, leafStride, codeStride;
     int D, maxDepth, tol, Ds, K;
     uint32_t *blockTot, *blockOff;
+    unsigned long long *blockOff64; // trees of more than 2^32 tokens (origTreeDepth > 28): the scan in 64 bits; index entries then
+    unsigned long long *idxBase;    // stay relative to their 4096-leaf block and idxBase[block] holds the block's stream offset
     unsigned long long *blockL1;   // per-block sum |recon - temp| after growth (reduced by k_emit_stats)
     uint8_t *blockAlive, *blockVal; // k_block_alive: flags, scalar above the block
     unsigned long long *blockSpine; // k_block_alive: tokens above depth D-10 owned by the block's first rank
@@ -1819,20 +1821,21 @@ __global__ void __launch_bounds__(1024)
 k_emit_scan(EmitArgs a, int64_t nblk)
 {
     __shared__ uint32_t shw[16];
-    __shared__ uint32_t carrySh;
+    __shared__ unsigned long long carrySh;
     const int brick = blockIdx.x;
     if (a.ctrls[brick].constBrick) return;
     const uint32_t *in = a.blockTot + (int64_t)brick * a.nEmitBlk;
     uint32_t *out = a.blockOff + (int64_t)brick * a.nEmitBlk;
+    unsigned long long *out64 = a.blockOff64 ? a.blockOff64 + (int64_t)brick * a.nEmitBlk : nullptr;
     if (threadIdx.x == 0) carrySh = 0;
     __syncthreads();
     for (int64_t base = 0; base < nblk; base += 1024) {
         int64_t i = base + threadIdx.x;
         uint32_t v = i < nblk ? in[i] : 0;
         uint32_t tot;
-        uint32_t ex = block_excl_scan_u32(v, shw, tot);
-        uint32_t carry = carrySh;
-        if (i < nblk) out[i] = carry + ex;
+        uint32_t ex = block_excl_scan_u32(v, shw, tot);        // 1024 blocks of at most 9 * 4096 tokens: fits 32 bits
+        unsigned long long carry = carrySh;
+        if (i < nblk) { out[i] = (uint32_t)(carry + ex); if (out64) out64[i] = carry + ex; }
         __syncthreads();
         if (threadIdx.x == 0) carrySh = carry + tot;
         __syncthreads();
@@ -1851,7 +1854,7 @@ k_emit_zero(EmitArgs a, int64_t nblk)
     const int brick = blockIdx.y;
     int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blk >= nblk || a.ctrls[brick].constBrick) return;
-    uint32_t g0 = a.blockOff[(int64_t)brick * a.nEmitBlk + blk];
+    const unsigned long long g0 = a.blockOff64 ? a.blockOff64[(int64_t)brick * a.nEmitBlk + blk] : a.blockOff[(int64_t)brick * a.nEmitBlk + blk];
     uint32_t tot = a.blockTot[(int64_t)brick * a.nEmitBlk + blk];
     uint32_t *W = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
     uint32_t *WR = a.treeR ? (uint32_t *)(a.treeR + (int64_t)brick * a.treeCap) : nullptr;
@@ -2222,7 +2225,8 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
     const int bflags = a.blockAlive[bo];
     const int bval = a.blockVal[bo];
     const unsigned long long upSpine = RANGE ? a.blockSpineR[bo] : a.blockSpine[bo];
-    const uint32_t g0 = a.blockOff[bo], tot = a.blockTot[bo];
+    const unsigned long long g0 = a.blockOff64 ? a.blockOff64[bo] : (unsigned long long)a.blockOff[bo];
+    const uint32_t tot = a.blockTot[bo];
     const uint32_t s = (blk << 6) + (uint32_t)t;                        // my depth-Ds (= D-6) subtree
     const int64_t io = (int64_t)brick * a.nIdx + s;
     const uint32_t local = a.idxOff[io];
@@ -2252,7 +2256,9 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
             const int code = (int)((cb[q] >> csh[q]) & 3u);
             val = (D - 12 + q) == 0 ? val : apply_code(val, code, dist[q]);
         }
-        a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? g0 + (uint32_t)nsp + local : VR_IDX_DEAD;
+        // (64-bit trees: the entry stays relative to the block, whose stream offset goes to idxBase)
+        a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? (a.idxBase ? 0u : (uint32_t)g0) + (uint32_t)nsp + local : VR_IDX_DEAD;
+        if (a.idxBase && t == 0) a.idxBase[bo] = g0;
         a.idxVal[io] = (uint8_t)val;
         uint32_t lo3 = 0, hi3 = 0;
 #pragma unroll
@@ -2267,13 +2273,13 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
     if (!(bflags & 1) || tot == 0) return;
     // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
     // would be a bug; it must surface as a failed parity check, not as a memory fault)
-    if (((unsigned long long)g0 + tot + 32ull) * 2ull > (unsigned long long)a.treeCap * 8ull) {
+    if ((g0 + tot + 32ull) * 2ull > (unsigned long long)a.treeCap * 8ull) {
         if (t == 0) atomicMax(&c.emitOverflow, 1);
         return;
     }
     const uint32_t cnt = (bflags & 2) ? tot - (uint32_t)nsp : 0u;      // staged tokens
     const int nws = (int)((cnt + 15u) >> 4);
-    const uint32_t phase = g0 & 15u;
+    const uint32_t phase = (uint32_t)(g0 & 15ull);
     const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
     uint32_t *G = (uint32_t *)((RANGE ? a.treeR : a.tree) + (int64_t)brick * a.treeCap) + (g0 >> 4);
     const PeStage stg = RANGE ? pe_stage_of(const_cast<uint8_t *>(a.tempR), a.heapStride, a.rbR, a.ctrlsR[brick].ra, a.ctrlsR[brick].rb,
@@ -2538,11 +2544,16 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     a.heapStride = bs->heapStride; a.leafStride = bs->leafStride; a.codeStride = bs->codeStride;
     a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
+    a.blockOff64 = bs->blockOff64; a.idxBase = bs->idxBase;
     a.blockL1 = bs->blockL1;
     a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine; a.blockSpineR = bs->blockSpineR;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.idxVal3 = bs->idxVal3; a.nIdx = bs->nIdx;
     a.chainLut = bs->chainLut;
+    if (bs->idx64 && !fused) {      // the level-synchronous emitters write absolute (32-bit) index entries: zero bases
+        a.blockOff64 = nullptr; a.idxBase = nullptr;
+        hipMemsetAsync(bs->idxBase, 0, (size_t)B * bs->nEmitBlk * sizeof(unsigned long long), st);
+    }
     const bool quad = (!mr || fused) && D >= 12 && bs->K >= 2;
     const int64_t nblk = cdiv((int64_t)1 << D, fused ? 4096 : (quad ? EMIT4_RANKS : EMIT_RANKS_PER_BLOCK));
     if (quad) hipLaunchKernelGGL(k_block_alive, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk, fused ? 12 : 10);   // + token counts
