@@ -850,6 +850,9 @@ k_decode_fine(TileArgs a)
 #define QD_TPW 16           // tiles per wave: amortises the table copy
 #endif
 #define QD_TS 68            // tile row stride in words (as FD_TS)
+#ifndef QD_PAIRSTEPS
+#define QD_PAIRSTEPS 1      // two steps per loop trip (independent chains interleave)
+#endif
 #ifndef QD_PF
 #define QD_PF 4             // steps the stream-word requests run ahead
 #endif
@@ -1045,6 +1048,48 @@ k_decode_quad(TileArgs a)
             };
 #pragma unroll
             for (int i = 0; i < QD_PF; ++i) request(i, i);
+            // one step's decode: my four voxels from my four stream words
+            const auto compute = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t b, int V3, bool live) -> uint32_t {
+                // my tokens: bits [0, 96) from my first token on
+                const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
+                               hh = __builtin_amdgcn_alignbit(w3, w2, b);
+                // my depth-(D-2) root (behind the ancestors' tokens)
+                int s4 = __builtin_amdgcn_sbfe((int)lo, p0, 2);
+                s4 = live ? s4 : -1;
+                const int V4 = med3i(mad24i((s4 + 1) >> 1, qd.d4, V3), 0, 255);
+                const bool dead = s4 == -1;
+                uint32_t used1, used2;
+                const uint32_t b01 = qd_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead, V4,
+                                             qd, chainS, used1);
+                const uint32_t p2 = p1 + used1;                   // <= 10 + 34
+                const bool q = p2 >= 32u;
+                const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
+                const uint32_t b23 = qd_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead, V4,
+                                             qd, chainS, used2);
+                return b01 | (b23 << 16);
+            };
+#if QD_PAIRSTEPS
+            // two steps per trip: their dependency chains (parse -> table lookups -> clamp-adds) are independent, so the
+            // scheduler can fill one's LDS waits with the other's arithmetic (a CU holds only 4 such waves per SIMD)
+#pragma unroll
+            for (int ip = 0; ip < 8; ++ip) {
+                const int i0 = 2 * ip, i1 = 2 * ip + 1, s0 = i0 % QD_PF, s1 = i1 % QD_PF;
+                const bool live0 = (((uint32_t)(liveMask >> (4 * i0))) & 15u) != 0u, live1 = (((uint32_t)(liveMask >> (4 * i1))) & 15u) != 0u;
+                const uint32_t a0 = qw[s0][0], a1 = qw[s0][1], a2 = qw[s0][2], a3 = qw[s0][3], ab = qb[s0];
+                const uint32_t c0 = qw[s1][0], c1 = qw[s1][1], c2 = qw[s1][2], c3 = qw[s1][3], cb = qb[s1];
+                const int aV = (int)qV[s0], cV = (int)qV[s1];
+                const bool aL = qLive[s0], cL = qLive[s1];
+                if (i0 + QD_PF < 16) request(i0 + QD_PF, s0);
+                if (i1 + QD_PF < 16) request(i1 + QD_PF, s1);
+                const int S0 = 4 * i0 + (lane >> 4), S1 = 4 * i1 + (lane >> 4);
+                if (live0 && live1) {
+                    const uint32_t r0 = compute(a0, a1, a2, a3, ab, aV, aL), r1 = compute(c0, c1, c2, c3, cb, cV, cL);
+                    tile[g * QD_TS + S0] = r0;
+                    tile[g * QD_TS + S1] = r1;
+                } else if (live0) tile[g * QD_TS + S0] = compute(a0, a1, a2, a3, ab, aV, aL);
+                else if (live1) tile[g * QD_TS + S1] = compute(c0, c1, c2, c3, cb, cV, cL);
+            }
+#else
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const bool liveStep = (((uint32_t)(liveMask >> (4 * it))) & 15u) != 0u;   // wave-uniform
@@ -1053,27 +1098,9 @@ k_decode_quad(TileArgs a)
                 const int V3 = (int)qV[slot];
                 const bool live = qLive[slot];
                 if (it + QD_PF < 16) request(it + QD_PF, slot);
-                if (liveStep) {
-                    const int S = 4 * it + (lane >> 4);
-                    // my tokens: bits [0, 96) from my first token on
-                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
-                                   hh = __builtin_amdgcn_alignbit(w3, w2, b);
-                    // my depth-(D-2) root (behind the ancestors' tokens)
-                    int s4 = __builtin_amdgcn_sbfe((int)lo, p0, 2);
-                    s4 = live ? s4 : -1;
-                    const int V4 = med3i(mad24i((s4 + 1) >> 1, qd.d4, V3), 0, 255);
-                    const bool dead = s4 == -1;
-                    uint32_t used1, used2;
-                    const uint32_t b01 = qd_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead, V4,
-                                                 qd, chainS, used1);
-                    const uint32_t p2 = p1 + used1;                   // <= 10 + 34
-                    const bool q = p2 >= 32u;
-                    const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
-                    const uint32_t b23 = qd_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead, V4,
-                                                 qd, chainS, used2);
-                    tile[g * QD_TS + S] = b01 | (b23 << 16);
-                }
+                if (liveStep) tile[g * QD_TS + 4 * it + (lane >> 4)] = compute(w0, w1, w2, w3, b, V3, live);
             }
+#endif
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
