@@ -1,11 +1,11 @@
-"""Turn the rocprofv3 outputs merged into gpurun_out/ (scratch/refresh_profiles.sh) into profiles/."""
+"""Turn the rocprofv3 outputs merged into gpurun_out/ (profiles/refresh_profiles.sh) into the committed profiles/r02_* files."""
 import csv, glob, json, collections, shutil, os
 R = "/root/repo/gpurun_out"
 P = "/root/repo/profiles"
-st = glob.glob(R + "/r1_stats/*/*kernel_stats.csv")[0]
-shutil.copy(st, P + "/r01_bench_kernel_stats.csv")
-ss = glob.glob(R + "/r1_stats_serial/*/*kernel_stats.csv")
-if ss: shutil.copy(ss[0], P + "/r01_bench_serial_kernel_stats.csv")
+st = glob.glob(R + "/r2_stats/*/*kernel_stats.csv")[0]
+shutil.copy(st, P + "/r02_bench_kernel_stats.csv")
+ss = glob.glob(R + "/r2_stats_serial/*/*kernel_stats.csv")
+if ss: shutil.copy(ss[0], P + "/r02_bench_serial_kernel_stats.csv")
 def pmc(d, name):
     acc = collections.defaultdict(list)
     f = glob.glob(R + "/" + d + "/*/*counter_collection.csv")[0]
@@ -13,23 +13,23 @@ def pmc(d, name):
         if r["Counter_Name"] == name and "vr::" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return acc
-fe, wr = pmc("r1_fetch", "FETCH_SIZE"), pmc("r1_write", "WRITE_SIZE")
+fe, wr = pmc("r2_fetch", "FETCH_SIZE"), pmc("r2_write", "WRITE_SIZE")
 kern = {}
 for k in sorted(set(fe) | set(wr)):
     e = {"launches": len(fe.get(k, wr.get(k)))}
     if k in fe: e["FETCH_SIZE_KiB_per_launch_avg"] = round(sum(fe[k]) / len(fe[k]), 1); e["FETCH_SIZE_KiB_per_launch_max"] = round(max(fe[k]), 1)
     if k in wr: e["WRITE_SIZE_KiB_per_launch_avg"] = round(sum(wr[k]) / len(wr[k]), 1); e["WRITE_SIZE_KiB_per_launch_max"] = round(max(wr[k]), 1)
     kern[k] = e
-dk = "vr::k_decode_fine"
+dk = "vr::k_decode_quad"
 dec = int((2 * kern[dk]["FETCH_SIZE_KiB_per_launch_avg"] + kern[dk]["WRITE_SIZE_KiB_per_launch_avg"]) * 1024)
 out = {
- "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-render",
+ "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-render --no-stream",
  "units": "counter values are KiB (rocprofv3 FETCH_SIZE / WRITE_SIZE); bytes = value * 1024",
- "note": "gfx950: WRITE_SIZE is exact for 16-byte-per-lane streaming stores; FETCH_SIZE under-reports wide coalesced reads by 2x and is uncalibrated for other widths (MI355X_MICROARCH.md, HBM section). k_decode_fine reads its stream words and the per-4-leaf counts as 16-byte-per-lane loads, so decode_traffic_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (the guide's correction); the per-kernel FETCH figures below are raw.",
+ "note": "gfx950: WRITE_SIZE is exact for 16-byte-per-lane streaming stores; FETCH_SIZE under-reports wide coalesced reads by 2x and is uncalibrated for other widths (MI355X_MICROARCH.md, HBM section). k_decode_quad reads its stream words and the per-4-leaf counts as 16-byte-per-lane loads (the 8-byte depth-(D-3) scalars and the 4-byte offsets are the smaller part), so decode_traffic_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (the guide's correction); the per-kernel FETCH figures below are raw.",
  "kernels": kern,
  "decode_traffic_bytes_per_launch": dec,
  "workload": "2048x2048x1920 rm_volume seed 12345, 960 bricks of 256x256x128, tolerance 1, maxEpochs 2",
 }
-json.dump(out, open(P + "/r01_pmc_hbm_traffic.json", "w"), indent=1)
-print("decode traffic", dec, "stats rows", sum(1 for _ in open(P + "/r01_bench_kernel_stats.csv")))
-print([l for l in open(R + "/r1_stats.log").read().splitlines() if l.startswith("{\"metric")][-1][:900])
+json.dump(out, open(P + "/r02_pmc_hbm_traffic.json", "w"), indent=1)
+print("decode traffic", dec, "stats rows", sum(1 for _ in open(P + "/r02_bench_kernel_stats.csv")))
+print([l for l in open(R + "/r2_stats.log").read().splitlines() if l.startswith("{\"metric")][-1][:900])

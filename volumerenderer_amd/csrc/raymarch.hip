@@ -77,21 +77,31 @@ struct SkipGrid { const uint8_t *g; int S, nx, ny, nz; };
 __global__ void __launch_bounds__(256)
 k_skip_grid(const uint8_t *__restrict__ vol, int X, int Y, int Z, int S, int nx, int ny, int nz, uint8_t *__restrict__ grid)
 {
-    // one wave per cell: lanes stride over its (S+1)^3 voxels, DPP-free shuffle reduction
+    // one wave per cell: a lane takes whole x-rows of the cell's (S+1)^2 (y, z) columns -- S + 1 consecutive bytes,
+    // fetched as aligned 8-byte pieces where the row allows it -- then a wave min / max
     const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (cell >= (int64_t)nx * ny * nz) return;
     const int cx = (int)(cell % nx), cy = (int)((cell / nx) % ny), cz = (int)(cell / ((int64_t)nx * ny));
     const int x0 = cx * S, y0 = cy * S, z0 = cz * S;
     const int ex = min(S + 1, X - x0), ey = min(S + 1, Y - y0), ez = min(S + 1, Z - z0);
-    int mn = 255, mx = 0;
-    const int n = ex * ey * ez;
-    for (int i = lane; i < n; i += 64) {
-        const int dx = i % ex, dy = (i / ex) % ey, dz = i / (ex * ey);
-        const int v = vol[(int64_t)(x0 + dx) + (int64_t)X * ((y0 + dy) + (int64_t)Y * (z0 + dz))];
-        mn = min(mn, v); mx = max(mx, v);
+    uint32_t mn = 255, mx = 0;
+    const bool wide = (S & 7) == 0 && (X & 7) == 0;          // rows start 8-byte aligned
+    for (int r = lane; r < ey * ez; r += 64) {
+        const uint8_t *row = vol + (int64_t)x0 + (int64_t)X * ((y0 + r % ey) + (int64_t)Y * (z0 + r / ey));
+        int i = 0;
+        if (wide)
+            for (; i + 8 <= ex; i += 8) {
+                const uint2 q = *(const uint2 *)(row + i);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t a = (q.x >> (8 * k)) & 255u, b = (q.y >> (8 * k)) & 255u;
+                    mn = min(mn, min(a, b)); mx = max(mx, max(a, b));
+                }
+            }
+        for (; i < ex; ++i) { const uint32_t v = row[i]; mn = min(mn, v); mx = max(mx, v); }
     }
-    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o)); }
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
     if (lane == 0) { grid[2 * cell] = (uint8_t)mn; grid[2 * cell + 1] = (uint8_t)mx; }
 }
 
