@@ -11,7 +11,9 @@ struct Stream2 {              // one 2-bit stream (mid, or MidRangeTree's half-r
     uint8_t *codes = nullptr; // B * codeStride   2-bit codes, four per byte (TwoBitArray packing), 1-based heap (BFS)
     uint8_t *recon[3] = {nullptr, nullptr, nullptr}; // B * leafStride each: parents + two level buffers
     Ctrl *ctrl = nullptr;     // B
-    uint8_t *tree = nullptr;  // B * treeCap      preorder stream, TwoBitArray packing
+    uint8_t *tree = nullptr;  // B * treeCap      the stream the decoders read: the reference's contiguous preorder stream (TwoBitArray
+                              //                  packing) or, after a fused build, its block-gapped form (BrickSet::gapped)
+    uint8_t *treeCompact = nullptr; // B * treeCap  fused builds: the contiguous stream, made on demand (compact_launch)
 };
 
 struct BrickSet {
@@ -70,6 +72,8 @@ struct BrickSet {
     uint32_t lutZeroRun = 0;    // chainLut[256]: table entries that would need the zero-run rewrite (always 0)
     bool encoderReady = false;  // every buffer of ensure_encoder_buffers (capi.hip) is allocated
     bool built = false, hostCtrlValid = false;
+    bool gapped = false;        // mid.tree / rng.tree hold 4096-leaf block strings in fixed slots (kd_encode.hip PE_WORDS)
+    bool compactValid = false;  // treeCompact holds the current build's contiguous stream
     bool foreign = false;       // stream installed by set_tree/open (no encoder state)
     std::vector<int64_t> openTreeBytes; // per brick: tree.bits size as the reference's open() would have it
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -80,6 +84,7 @@ struct BrickSet {
 
 // kd_encode.hip
 int encode_launch(BrickSet *bs, const uint8_t *voxDev, hipStream_t st);
+int compact_launch(BrickSet *bs, hipStream_t st);   // fused builds: contiguous stream(s) into Stream2::treeCompact
 // kd_decode.hip
 int decode_launch(BrickSet *bs, uint8_t *outDev, int cutDepth, hipStream_t st, bool rangeStream = false);
 int cut_values_from_stream(BrickSet *bs, const uint8_t *treeHost, int64_t numActive, const uint8_t *dmapHost, int cut,

@@ -103,6 +103,7 @@ vr_status vr_download(void *dst, const void *src, int64_t bytes, void *stream)
 
 static void free_stream2(Stream2 &s)
 {
+    hipFree(s.treeCompact);
     hipFree(s.temp); hipFree(s.codes);
     for (int i = 0; i < 3; ++i) hipFree(s.recon[i]);
     hipFree(s.ctrl); hipFree(s.tree);
@@ -238,6 +239,10 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     b.codeStride = ((b.heapStride + 15) / 16) * 4;
     const int64_t numMax = b.heapStride - 1 + VR_CHAIN_LEVELS * b.leafStride; // numMaxNodes R.cpp:35
     b.treeCap = ((numMax + 15) / 16 + 2) * 4 + 256;   // slack: the decoder stages whole words past a run's end
+    if (b.D >= 12) {   // a fused build keeps every 4096-leaf block's string in a fixed slot of 2320 words (kd_encode.hip PE_WORDS)
+        const int64_t gappedBytes = ((int64_t)1 << (b.D - 12)) * 2320 * 4 + 256;
+        if (gappedBytes > b.treeCap) b.treeCap = gappedBytes;
+    }
     b.nIdx = (int64_t)1 << b.Ds;
     vr_status rc = alloc_stream2(b, b.mid, false);
     if (rc == VR_OK) {
@@ -348,14 +353,40 @@ vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
     return VR_OK;
 }
 
+// The contiguous preorder stream (the reference's tree.bits) of stream s: after a fused build the device holds the
+// block-gapped form the decoders read; the reference's layout is made here, once per build, when the host asks for it.
+static vr_status contiguous_stream(BrickSet &b, Stream2 &s, const uint8_t **base)
+{
+    if (!s.tree) return VR_ERR_STATE;
+    if (!b.gapped) { *base = s.tree; return VR_OK; }
+    if (!b.compactValid) {
+        const bool mr = b.variant == VR_VARIANT_MIDRANGE;
+        if (!b.mid.treeCompact) HIPCHK(hipMalloc(&b.mid.treeCompact, (size_t)b.B * b.treeCap));
+        if (mr && !b.rng.treeCompact) HIPCHK(hipMalloc(&b.rng.treeCompact, (size_t)b.B * b.treeCap));
+        HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
+        const int rc = compact_launch(&b, (hipStream_t)b.lastStream);
+        HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
+        if (rc != 0) return VR_ERR_NO_DEVICE;
+        b.compactValid = true;
+        // (an emit overflow would have been flagged in the control blocks: re-read them)
+        HIPCHK(hipMemcpy(b.hostCtrl.data(), b.mid.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
+        b.hostCtrlValid = true;
+    }
+    *base = s.treeCompact;
+    return VR_OK;
+}
+
 static vr_status get_tree_common(BrickSet &b, Stream2 &s, int brick, uint8_t *dst, int64_t cap)
 {
     vr_status rc = sync_ctrl(b);
     if (rc != VR_OK) return rc;
     int64_t bytes = ((int64_t)b.hostCtrl[brick].numActive + 3) / 4;
     if (!dst || cap < bytes) return VR_ERR_INVALID;
-    if (!s.tree) return VR_ERR_STATE;
-    HIPCHK(hipMemcpy(dst, s.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    const uint8_t *base = nullptr;
+    rc = contiguous_stream(b, s, &base);
+    if (rc != VR_OK) return rc;
+    if (b.hostCtrl[brick].emitOverflow) return VR_ERR_STATE;
+    HIPCHK(hipMemcpy(dst, base + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
     return VR_OK;
 }
 
@@ -415,8 +446,12 @@ vr_status vr_brickset_get_packed4(vr_brickset *h, int32_t brick, uint8_t *dst, i
     if (cap < v) return VR_ERR_INVALID;
     const int64_t bytes = (n + 3) / 4;
     std::vector<uint8_t> m((size_t)bytes), r((size_t)bytes);
-    HIPCHK(hipMemcpy(m.data(), b.mid.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(r.data(), b.rng.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    const uint8_t *baseM = nullptr, *baseR = nullptr;
+    rc = contiguous_stream(b, b.mid, &baseM);
+    if (rc == VR_OK) rc = contiguous_stream(b, b.rng, &baseR);
+    if (rc != VR_OK) return rc;
+    HIPCHK(hipMemcpy(m.data(), baseM + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r.data(), baseR + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
     memset(dst, 0, (size_t)v);
     auto get = [](const std::vector<uint8_t> &a, int64_t i) { return (a[(size_t)(i >> 2)] >> ((i & 3) * 2)) & 3; };
     int64_t o = 0;
@@ -479,6 +514,7 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     BrickSet &b = h->s;
     if (map_len < b.maxDepth + 1 || num_active <= 0) return VR_ERR_INVALID;
     if (num_active >= (1ll << 32)) return VR_ERR_UNSUPPORTED;      // the host-side index of a foreign stream is 32-bit
+    if (b.built && !b.foreign) return VR_ERR_STATE;                // streams are installed into a fresh set, not beside built trees
     const int64_t need = (num_active + 3) / 4;
     if (tree_bytes < need || need > b.treeCap) return VR_ERR_FORMAT;
     std::vector<uint32_t> offs;
@@ -511,6 +547,7 @@ vr_status vr_brickset_set_tree(vr_brickset *h, int32_t brick, const uint8_t *tre
     b.built = true;
     b.hostCtrlValid = true;
     b.foreign = true;
+    b.gapped = false;          // an installed stream is the contiguous one; its index points into it
     if (b.idx64) {      // absolute 32-bit offsets from the host parse: bases are zero
         if (!b.idxBase) { b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256; HIPCHK(hipMalloc(&b.idxBase, (size_t)b.B * b.nEmitBlk * sizeof(unsigned long long))); }
         HIPCHK(hipMemset(b.idxBase, 0, (size_t)b.B * b.nEmitBlk * sizeof(unsigned long long)));
@@ -540,7 +577,10 @@ vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
     const int64_t bytes = ((int64_t)c.numActive + 3) / 4;
     if (bytes == 0) return VR_ERR_STATE;
     std::vector<uint8_t> tree((size_t)bytes);
-    HIPCHK(hipMemcpy(tree.data(), b.mid.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    const uint8_t *baseM = nullptr;
+    rc = contiguous_stream(b, b.mid, &baseM);
+    if (rc != VR_OK) return rc;
+    HIPCHK(hipMemcpy(tree.data(), baseM + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
     // MidRangeTree::save (M.cpp:753-785): same header, then distanceMap, distanceMap_range, tree, tree_range
     const bool mrFile = b.variant == VR_VARIANT_MIDRANGE;
     std::vector<uint8_t> treeR;
@@ -548,7 +588,10 @@ vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
     if (mrFile) {
         if (b.foreign && !b.foreignRange) return VR_ERR_STATE;
         treeR.resize((size_t)bytes);
-        HIPCHK(hipMemcpy(treeR.data(), b.rng.tree + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+        const uint8_t *baseR = nullptr;
+        rc = contiguous_stream(b, b.rng, &baseR);
+        if (rc != VR_OK) return rc;
+        HIPCHK(hipMemcpy(treeR.data(), baseR + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&cr, b.rng.ctrl + brick, sizeof(Ctrl), hipMemcpyDeviceToHost));
     }
     FILE *f = fopen(path, "wb");

@@ -1370,11 +1370,13 @@ __device__ __forceinline__ uint32_t block4_excl_scan_u32(uint32_t v, uint32_t *s
 // One block owns a depth-(D-12) subtree: 4096 leaves, 16 per thread.  It prunes the twelve levels
 // bottom-up like k_prune12 (the four above the leaves in registers, the other eight in LDS), and then,
 // top-down, writes the subtree's own preorder token string -- assuming its root is live -- into LDS
-// and from there into a per-block staging area.  k_concat12 later moves the strings of the live
-// blocks to their final offsets.  The leaf arrays are read once; the staging area is memory the level
-// loop has left free: the internal half of the midrange heap and the two spare reconstruction buffers
-// (4 KiB each per block; a block's string is at most 4095 + 8 * 4096 tokens = 9216 bytes).
+// and from there into the block's slot of the brick's stream buffer: slot b starts at word b * PE_WORDS
+// (a block's string is at most 4095 + 8 * 4096 tokens = 9216 bytes).  That block-gapped buffer IS what the decoders
+// read (k_index12 points the decode index at the slots); the reference's contiguous layout (R.cpp:631-724 writes one
+// array) is produced from it by k_concat12 when somebody asks for the bytes -- vr_brickset_get_tree, save,
+// get_packed4 -- not on the build -> levelCut path, where that copy was 4.5 ms of a 43 ms build.
 #define PE_WORDS 2320
+#define PE_TOKENS (PE_WORDS * 16)
 
 struct PruneEmitArgs {
     int D, tol, maxDepth;
@@ -1394,25 +1396,9 @@ struct PruneEmitArgs {
     Ctrl *ctrlsR;
     uint8_t *tempR, *codesR;
     ReconBufs rbR;
+    uint8_t *gap, *gapR;           // the streams' block-gapped buffers (Stream2::tree)
+    int64_t treeCap;
 };
-
-// The three 4 KiB pieces of a block's staging area, resolved once per thread: indexing ReconBufs (a kernel
-// argument) with a run-time index inside a loop would be a load from the argument segment per access.
-struct PeStage { uint32_t *p0, *p1, *p2; };
-__device__ __forceinline__ PeStage pe_stage_of(uint8_t *temp, int64_t heapStride, const ReconBufs &rb, int ra, int rbI,
-                                               int64_t leafStride, int brick, uint32_t blk)
-{
-    PeStage s;
-    uint8_t *b1 = ra == 0 ? rb.b[0] : (ra == 1 ? rb.b[1] : rb.b[2]), *b2 = rbI == 0 ? rb.b[0] : (rbI == 1 ? rb.b[1] : rb.b[2]);
-    s.p0 = (uint32_t *)(temp + (int64_t)brick * heapStride + (int64_t)blk * 4096);
-    s.p1 = (uint32_t *)(b1 + (int64_t)brick * leafStride + (int64_t)blk * 4096);
-    s.p2 = (uint32_t *)(b2 + (int64_t)brick * leafStride + (int64_t)blk * 4096);
-    return s;
-}
-__device__ __forceinline__ uint32_t *pe_stage(const PeStage &s, uint32_t w)
-{
-    return (w < 1024u ? s.p0 : (w < 2048u ? s.p1 : s.p2)) + (w & 1023u);
-}
 
 __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
 {   // v: at most 44 bits of tokens
@@ -1443,7 +1429,7 @@ k_prune_emit12(PruneEmitArgs a)
     __shared__ uint32_t shw[4];
     const int brick = blockIdx.y, t = threadIdx.x, D = a.D, tol = a.tol;
     Ctrl &c = a.ctrls[brick];
-    const int cConst = c.constBrick, cPar = c.par, cRa = c.ra, cRb = c.rb;     // one scalar round trip
+    const int cConst = c.constBrick, cPar = c.par;     // one scalar round trip
     if (cConst) return;
     const uint32_t blk = blockIdx.x, base = blk << 12;
     uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
@@ -1464,11 +1450,9 @@ k_prune_emit12(PruneEmitArgs a)
     uint8_t *CbR = RANGE ? a.codesR + (int64_t)brick * a.codeStride : nullptr;
     uint32_t upBR = 0, c4BR = 0, c3BR = 0, c2BR = 0, c1HR = 0, cpkR = 0;
     uint4 tvR = make_uint4(0, 0, 0, 0), rvR = make_uint4(0, 0, 0, 0);
-    int cRaR = 0, cRbR = 0;
     if (RANGE) {
         const Ctrl &cr = a.ctrlsR[brick];
         const int cParR = cr.par;
-        cRaR = cr.ra; cRbR = cr.rb;
         upBR = CbR[niU >> 2]; c4BR = CbR[n4 >> 2]; c3BR = CbR[n3 >> 2]; c2BR = CbR[n2 >> 2];
         c1HR = *(const uint16_t *)(CbR + (n1 >> 2));
         cpkR = *(const uint32_t *)(CbR + (li >> 2));
@@ -1490,16 +1474,14 @@ k_prune_emit12(PruneEmitArgs a)
         if (RANGE) {        // the range stream's copy of that one token
             if (t == 0) {
                 cset3(CbR, ((int64_t)1 << (D - 12)) + blk);
-                const PeStage stg = pe_stage_of(a.tempR, a.heapStride, a.rbR, cRaR, cRbR, a.leafStride, brick, blk);
-                *pe_stage(stg, 0) = 3u;
+                *((uint32_t *)(a.gapR + (int64_t)brick * a.treeCap) + (size_t)blk * PE_WORDS) = 3u;
             }
             return;
         }
         if (t == 0) {
             cset3(Cb, ((int64_t)1 << (D - 12)) + blk);
             a.subTok[(int64_t)brick * a.nEmitBlk + blk] = 1;
-            const PeStage stg = pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
-            *pe_stage(stg, 0) = 3u;
+            *((uint32_t *)(a.gap + (int64_t)brick * a.treeCap) + (size_t)blk * PE_WORDS) = 3u;
         }
         if (t < 4) a.blockL1[(int64_t)brick * a.nEmitBlk + (size_t)blk * 4 + t] = stat_pack(0, 0, 0);
         if (t < 64) a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + t] = VR_IDX_DEAD;
@@ -1780,16 +1762,11 @@ k_prune_emit12(PruneEmitArgs a)
         a.fineIdx[((int64_t)brick * a.nIdx + (base >> 6)) * 4 + t] = f0 | (f1 << 8) | (f2 << 16) | (f3 << 24);
     }
     __syncthreads();
-    const uint32_t nw = (tot + 15u) >> 4;
-    const PeStage stg = RANGE ? pe_stage_of(a.tempR, a.heapStride, a.rbR, cRaR, cRbR, a.leafStride, brick, blk)
-                              : pe_stage_of(a.temp, a.heapStride, a.rb, cRa, cRb, a.leafStride, brick, blk);
-    // piece by piece (three 4 KiB areas): a per-word choice between three 64-bit pointers cost more than the copy
-#pragma unroll 1
-    for (uint32_t k = 0; k * 256u < nw; ++k) {          // four trips per piece: the piece is uniform in a trip
-        uint32_t *pp = k < 4u ? stg.p0 : (k < 8u ? stg.p1 : stg.p2);
-        const uint32_t i = k * 256u + t;
-        if (i < nw) pp[(k & 3u) * 256u + t] = W[i];
-    }
+    // the block's slot of the gapped stream buffer; one word past the string too, so that no stale token of an earlier
+    // build sits right behind it (the decoders fetch whole words past a run's end; what they fetch there is never used)
+    const uint32_t nw = min((tot + 15u) / 16u + 1u, (uint32_t)PE_WORDS);
+    uint32_t *slot = (uint32_t *)((RANGE ? a.gapR : a.gap) + (int64_t)brick * a.treeCap) + (size_t)blk * PE_WORDS;
+    for (uint32_t i = t; i < nw; i += 256u) slot[i] = W[i];
 }
 
 
@@ -2207,26 +2184,19 @@ k_emit4(EmitArgs a)
     }
 }
 
-// Moves the block strings k_prune_emit12 staged to their final places: block b contributes the upper spine
-// its first rank owns (k_block_alive) and, if its depth-(D-12) root is live, its staged string, at token
-// offset blockOff[b].  Also turns the block-local index offsets into stream offsets and fills the index
-// values (the scalar decoded down to depth Ds; codes under a pruned node are all 3, so the walk is the
-// same for live and dead entries).
-template <bool RANGE>        // RANGE: MidRangeTree's second stream -- same offsets and shape, its own staged strings and spine; no index
+// The decode index of a fused build: block-local offsets -> offsets into the gapped stream buffer (slot b starts at
+// token b * PE_TOKENS), the scalar decoded down to depth Ds, and the scalars of the eight depth-(D-3) nodes below it
+// (k_decode_quad).  Codes under a pruned node are all 3, so the walks are the same for live and dead entries.
 __global__ void __launch_bounds__(64)
-k_concat12(EmitArgs a)       // one wave per block string: many small workgroups in flight hide the memory round trips
+k_index12(EmitArgs a)
 {
     const int brick = blockIdx.y, t = threadIdx.x, D = a.D;
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
     const uint32_t blk = blockIdx.x;
     const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
-    // round trip 1: the block record, my index entry and the seven codes above it (all independent)
     const int bflags = a.blockAlive[bo];
     const int bval = a.blockVal[bo];
-    const unsigned long long upSpine = RANGE ? a.blockSpineR[bo] : a.blockSpine[bo];
-    const unsigned long long g0 = a.blockOff64 ? a.blockOff64[bo] : (unsigned long long)a.blockOff[bo];
-    const uint32_t tot = a.blockTot[bo];
     const uint32_t s = (blk << 6) + (uint32_t)t;                        // my depth-Ds (= D-6) subtree
     const int64_t io = (int64_t)brick * a.nIdx + s;
     const uint32_t local = a.idxOff[io];
@@ -2247,29 +2217,45 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
                   n3 = ((int64_t)1 << (D - 3)) + 8 * (int64_t)s;
     const uint32_t c5 = (uint32_t)Cb[n5 >> 2] >> ((int)(n5 & 3) * 2), c4 = Cb[n4 >> 2], c3 = *(const uint16_t *)(Cb + (n3 >> 2));
     const int dl5 = c.distanceMap[D - 5], dl4 = c.distanceMap[D - 4], dl3 = c.distanceMap[D - 3];
+    int val = bval;                             // scalar of the block root's parent
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int code = (int)((cb[q] >> csh[q]) & 3u);
+        val = (D - 12 + q) == 0 ? val : apply_code(val, code, dist[q]);
+    }
+    // (64-bit trees: the entry stays relative to the block, whose slot offset goes to idxBase)
+    a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? (a.idxBase ? 0u : blk * (uint32_t)PE_TOKENS) + local : VR_IDX_DEAD;
+    if (a.idxBase && t == 0) a.idxBase[bo] = (unsigned long long)blk * PE_TOKENS;
+    a.idxVal[io] = (uint8_t)val;
+    uint32_t lo3 = 0, hi3 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int v = apply_code(val, (int)((c5 >> (2 * (i >> 2))) & 3u), dl5);
+        v = apply_code(v, (int)((c4 >> (2 * (i >> 1))) & 3u), dl4);
+        v = apply_code(v, (int)((c3 >> (2 * i)) & 3u), dl3);
+        if (i < 4) lo3 |= (uint32_t)v << (8 * i); else hi3 |= (uint32_t)v << (8 * (i - 4));
+    }
+    *(uint2 *)(a.idxVal3 + io * 8) = make_uint2(lo3, hi3);
+}
+
+// The reference's layout on demand: block b contributes the upper spine its first rank owns (k_block_alive) and, if its
+// depth-(D-12) root is live, its string from the gapped buffer, at token offset blockOff[b] of the contiguous stream
+// (a.tree / a.treeR here = the destination).
+template <bool RANGE>        // RANGE: MidRangeTree's second stream -- same offsets and shape, its own strings and spine
+__global__ void __launch_bounds__(64)
+k_concat12(EmitArgs a, const uint8_t *__restrict__ gap)       // one wave per block string
+{
+    const int brick = blockIdx.y, t = threadIdx.x;
+    Ctrl &c = a.ctrls[brick];
+    if (c.constBrick) return;
+    const uint32_t blk = blockIdx.x;
+    const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
+    const int bflags = a.blockAlive[bo];
+    const unsigned long long upSpine = RANGE ? a.blockSpineR[bo] : a.blockSpine[bo];
+    const unsigned long long g0 = a.blockOff64 ? a.blockOff64[bo] : (unsigned long long)a.blockOff[bo];
+    const uint32_t tot = a.blockTot[bo];
     const int nsp = (int)(upSpine >> 56);
     const unsigned long long spine = upSpine & 0x00FFFFFFFFFFFFFFull;
-    if (!RANGE) {
-        int val = bval;                             // scalar of the block root's parent
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const int code = (int)((cb[q] >> csh[q]) & 3u);
-            val = (D - 12 + q) == 0 ? val : apply_code(val, code, dist[q]);
-        }
-        // (64-bit trees: the entry stays relative to the block, whose stream offset goes to idxBase)
-        a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? (a.idxBase ? 0u : (uint32_t)g0) + (uint32_t)nsp + local : VR_IDX_DEAD;
-        if (a.idxBase && t == 0) a.idxBase[bo] = g0;
-        a.idxVal[io] = (uint8_t)val;
-        uint32_t lo3 = 0, hi3 = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int v = apply_code(val, (int)((c5 >> (2 * (i >> 2))) & 3u), dl5);
-            v = apply_code(v, (int)((c4 >> (2 * (i >> 1))) & 3u), dl4);
-            v = apply_code(v, (int)((c3 >> (2 * i)) & 3u), dl3);
-            if (i < 4) lo3 |= (uint32_t)v << (8 * i); else hi3 |= (uint32_t)v << (8 * (i - 4));
-        }
-        *(uint2 *)(a.idxVal3 + io * 8) = make_uint2(lo3, hi3);
-    }
     if (!(bflags & 1) || tot == 0) return;
     // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
     // would be a bug; it must surface as a failed parity check, not as a memory fault)
@@ -2277,30 +2263,28 @@ k_concat12(EmitArgs a)       // one wave per block string: many small workgroups
         if (t == 0) atomicMax(&c.emitOverflow, 1);
         return;
     }
-    const uint32_t cnt = (bflags & 2) ? tot - (uint32_t)nsp : 0u;      // staged tokens
+    const uint32_t cnt = (bflags & 2) ? tot - (uint32_t)nsp : 0u;      // tokens of the block's own string
     const int nws = (int)((cnt + 15u) >> 4);
     const uint32_t phase = (uint32_t)(g0 & 15ull);
     const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
     uint32_t *G = (uint32_t *)((RANGE ? a.treeR : a.tree) + (int64_t)brick * a.treeCap) + (g0 >> 4);
-    const PeStage stg = RANGE ? pe_stage_of(const_cast<uint8_t *>(a.tempR), a.heapStride, a.rbR, a.ctrlsR[brick].ra, a.ctrlsR[brick].rb,
-                                            a.leafStride, brick, blk)
-                              : pe_stage_of(const_cast<uint8_t *>(a.temp), a.heapStride, a.rb, c.ra, c.rb, a.leafStride, brick, blk);
+    const uint32_t *slot = (const uint32_t *)(gap + (int64_t)brick * a.treeCap) + (size_t)blk * PE_WORDS;
     for (uint32_t i0 = 0; i0 < nwo; i0 += 256) {        // four words per lane and trip: eight loads in flight
         uint32_t lo[4], hi[4];
         int sbv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
-            const int so = 2 * (16 * (int)i - (int)phase) - 2 * nsp, sw = so >> 5;     // staged bit offset (floor division)
+            const int so = 2 * (16 * (int)i - (int)phase) - 2 * nsp, sw = so >> 5;     // bit offset in the string (floor division)
             sbv[u] = so & 31;
-            lo[u] = (cnt && i < nwo && sw >= 0 && sw < nws) ? *pe_stage(stg, (uint32_t)sw) : 0u;
-            hi[u] = (cnt && i < nwo && sw + 1 >= 0 && sw + 1 < nws) ? *pe_stage(stg, (uint32_t)(sw + 1)) : 0u;
+            lo[u] = (cnt && i < nwo && sw >= 0 && sw < nws) ? slot[sw] : 0u;
+            hi[u] = (cnt && i < nwo && sw + 1 >= 0 && sw + 1 < nws) ? slot[sw + 1] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
             if (i >= nwo) continue;
-            const int bo2 = 2 * (16 * (int)i - (int)phase);            // bit offset of this word in spine ++ staged
+            const int bo2 = 2 * (16 * (int)i - (int)phase);            // bit offset of this word in spine ++ string
             uint32_t v = sbv[u] ? (lo[u] >> sbv[u]) | (hi[u] << (32 - sbv[u])) : lo[u];
             if (nsp) v |= bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
             if (i == 0 || i == nwo - 1) { if (v) atomicOr(&G[i], v); }
@@ -2420,6 +2404,43 @@ static bool dbg_sync(hipStream_t st, const char *phase)
     return e == hipSuccess;
 }
 
+static void fill_emit_args(BrickSet *bs, EmitArgs &a)
+{
+    const bool mr = bs->variant == 2;
+    a.codes = bs->mid.codes; a.codesR = mr ? bs->rng.codes : nullptr;
+    a.temp = bs->mid.temp; a.tempR = mr ? bs->rng.temp : nullptr;
+    a.rb = ReconBufs{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
+    a.rbR = ReconBufs{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
+    a.ctrls = bs->mid.ctrl; a.ctrlsR = mr ? bs->rng.ctrl : nullptr;
+    a.heapStride = bs->heapStride; a.leafStride = bs->leafStride; a.codeStride = bs->codeStride;
+    a.D = bs->D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
+    a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
+    a.blockOff64 = bs->blockOff64; a.idxBase = bs->idxBase;
+    a.blockL1 = bs->blockL1;
+    a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine; a.blockSpineR = bs->blockSpineR;
+    a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
+    a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.idxVal3 = bs->idxVal3; a.nIdx = bs->nIdx;
+    a.chainLut = bs->chainLut;
+}
+
+// The reference's contiguous stream(s) of a fused build, into bs->mid.treeCompact (and rng.treeCompact): zero the words
+// two blocks share, then one wave per block copies spine + string to blockOff[b].  Runs when the host asks for bytes.
+int compact_launch(BrickSet *bs, hipStream_t st)
+{
+    const int D = bs->D, B = bs->B;
+    const bool mr = bs->variant == 2;
+    EmitArgs a;
+    fill_emit_args(bs, a);
+    a.tree = bs->mid.treeCompact; a.treeR = mr ? bs->rng.treeCompact : nullptr;
+    const int64_t nblk = cdiv((int64_t)1 << D, 4096);
+    hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
+    hipLaunchKernelGGL(k_concat12<false>, dim3((unsigned)nblk, B), dim3(64), 0, st, a, bs->mid.tree);
+    if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3((unsigned)nblk, B), dim3(64), 0, st, a, bs->rng.tree);
+    hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.treeCompact,
+                       bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
+    return launch_status("compact");
+}
+
 int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
 {
     const int D = bs->D, B = bs->B;
@@ -2513,6 +2534,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.fineIdx = (uint32_t *)bs->fineIdx;
         pa.ctrlsR = mr ? bs->rng.ctrl : nullptr; pa.tempR = mr ? bs->rng.temp : nullptr; pa.codesR = mr ? bs->rng.codes : nullptr;
         pa.rbR = rbR;
+        pa.gap = bs->mid.tree; pa.gapR = mr ? bs->rng.tree : nullptr; pa.treeCap = bs->treeCap;
         hipLaunchKernelGGL(k_prune_emit12<false>, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
         if (mr) hipLaunchKernelGGL(k_prune_emit12<true>, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
         pruneFrom = D - 13;
@@ -2537,19 +2559,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     dbg_sync(st, "prune");
     // ---- CONVERT
     EmitArgs a;
-    a.codes = bs->mid.codes; a.codesR = mr ? bs->rng.codes : nullptr;
-    a.temp = bs->mid.temp; a.tempR = mr ? bs->rng.temp : nullptr;
-    a.rb = rb; a.rbR = rbR;
-    a.ctrls = bs->mid.ctrl; a.ctrlsR = mr ? bs->rng.ctrl : nullptr;
-    a.heapStride = bs->heapStride; a.leafStride = bs->leafStride; a.codeStride = bs->codeStride;
-    a.D = D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
-    a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
-    a.blockOff64 = bs->blockOff64; a.idxBase = bs->idxBase;
-    a.blockL1 = bs->blockL1;
-    a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine; a.blockSpineR = bs->blockSpineR;
-    a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
-    a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.idxVal3 = bs->idxVal3; a.nIdx = bs->nIdx;
-    a.chainLut = bs->chainLut;
+    fill_emit_args(bs, a);
     if (bs->idx64 && !fused) {      // the level-synchronous emitters write absolute (32-bit) index entries: zero bases
         a.blockOff64 = nullptr; a.idxBase = nullptr;
         hipMemsetAsync(bs->idxBase, 0, (size_t)B * bs->nEmitBlk * sizeof(unsigned long long), st);
@@ -2561,13 +2571,16 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     dbg_sync(st, "block_alive/count");
     hipLaunchKernelGGL(k_emit_scan, dim3(B), dim3(1024), 0, st, a, nblk);
     dbg_sync(st, "emit_scan");
-    hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-    if (fused) {
-        hipLaunchKernelGGL(k_concat12<false>, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
-        if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
+    // fused: the strings stay in their slots of the gapped buffer, the decode index points there (k_index12); the
+    // contiguous stream is made when the host asks for it (compact_launch)
+    bs->gapped = fused;
+    bs->compactValid = false;
+    if (fused) hipLaunchKernelGGL(k_index12, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
+    else {
+        hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
+        if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     }
-    else if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_emit_write, dim3((unsigned)nblk, B), dim3(EMIT_RANKS_PER_BLOCK), 0, st, a);
     // statistics records: one per 1024 leaves from k_prune12, one per 256 from k_prune_leaf
     hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, (int64_t)(D >= 12 ? cdiv((int64_t)1 << D, 1024) : cdiv((int64_t)1 << D, 256)));
     hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.tree,
