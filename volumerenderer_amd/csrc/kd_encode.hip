@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t pk_half_range(vr_s16x2 mn, vr_s16x2 mx) { re
 __global__ void __launch_bounds__(256)
 k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__restrict__ temp, int64_t heapStride,
             uint8_t *__restrict__ tempRange, uint8_t *__restrict__ outMin, uint8_t *__restrict__ outMax,
-            int64_t outStride)
+            int64_t outStride, uint8_t *__restrict__ blockFlag)
 {
     __shared__ __attribute__((aligned(16))) uint8_t leaf[4096];
     __shared__ uint32_t waveMM[4];
@@ -226,11 +226,30 @@ k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__re
         if (TR) TR[o] = (uint8_t)((rbm - ra) >> 1);
         outMin[(int64_t)brick * outStride + (base >> 12)] = (uint8_t)ra;
         outMax[(int64_t)brick * outStride + (base >> 12)] = (uint8_t)rbm;
+        // SkipBlocks: bit 0 = every voxel of the block has one value (the skip bit is set, or not, by the level loop)
+        if (blockFlag) blockFlag[(int64_t)brick * ((int64_t)1 << (D - 12)) + (base >> 12)] = ra == rbm ? 1u : 0u;
     }
 }
 
 // --------------------------------------------------------------- compress ----
 struct ReconBufs { uint8_t *b[3]; };
+
+// Constant 4096-leaf blocks (kd_encode.hip k_pyramid12 sees min == max at their depth-(D-12) root) whose depth-(D-3)
+// nodes are already reconstructed exactly: every node below has truth == parent's reconstruction, so it keeps
+// (code 0), reproduces the value and adds no error at ANY distance (encodeNode R.cpp:457-502 with pd = 0), and the
+// running-mean estimator never counts it (R.cpp:415-455).  The level loop does not touch such a block at levels D-1 and
+// D at all -- no loads, no stores; its codes and reconstruction there stay unwritten and nothing reads them: the fused
+// prune/emit kernel takes the block as one pruned subtree from the flag.  flag[block]: bit 0 constant (k_pyramid12),
+// bit 1 skip (set by the level D-2 fill, whose wave is exactly one block and sees truth == parents there).
+struct SkipBlocks {
+    uint8_t *flag;        // B * nBlk, or null: feature off (MidRangeTree, tolerance 0, small trees, general extents)
+    int64_t nBlk;
+    int Dm2;              // D - 2
+};
+__device__ __forceinline__ bool skip_block(const SkipBlocks &sk, int brick, int d, uint32_t node)
+{   // node of level d (d == D-1 or D) inside a skipped block?
+    return sk.flag && d > sk.Dm2 && (sk.flag[(int64_t)brick * sk.nBlk + (node >> (10 + d - sk.Dm2))] & 2u) != 0u;
+}
 
 __device__ inline int phys_buf(const Ctrl &c, int role) { return role == 0 ? c.ra : c.rb; }
 
@@ -303,19 +322,25 @@ __device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int
 
 // exact in-order walk of nodes [lo, hi) by one wave; (S,C) are wave-uniform
 __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, uint32_t lo,
-                                       uint32_t hi, unsigned long long &S, uint32_t &C, int lane)
+                                       uint32_t hi, unsigned long long &S, uint32_t &C, int lane, const SkipBlocks &sk, int brick)
 {
-    // the next 64 nodes are in flight while these are decided (the walk is latency-bound otherwise)
-    int tn = lo + lane < hi ? T[lo + lane] : 0, pn = (lo + lane < hi && d > 0) ? P[(lo + lane) >> 1] : 0;
+    // the next 64 nodes are in flight while these are decided (the walk is latency-bound otherwise); chunks inside a
+    // skipped block (SkipBlocks: nothing there counts, and its parents' reconstruction is not in memory) are passed over
+    const bool sk0 = skip_block(sk, brick, d, lo);
+    int tn = (!sk0 && lo + lane < hi) ? T[lo + lane] : 0, pn = (!sk0 && lo + lane < hi && d > 0) ? P[(lo + lane) >> 1] : 0;
+    bool skipThis = sk0;
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t i = base + lane;
         bool valid = i < hi;
         const int t = tn, p = pn;
+        const bool skipped = skipThis;
         {
             const uint32_t i2 = i + 64;
-            tn = i2 < hi ? T[i2] : 0;
-            pn = (i2 < hi && d > 0) ? P[i2 >> 1] : 0;
+            skipThis = base + 64 < hi && skip_block(sk, brick, d, base + 64);
+            tn = (!skipThis && i2 < hi) ? T[i2] : 0;
+            pn = (!skipThis && i2 < hi && d > 0) ? P[i2 >> 1] : 0;
         }
+        if (skipped) continue;
         int pd = p > t ? p - t : t - p;
         bool forced = (t > p && 2 * t - p > 255) || (t < p && 2 * t < p);
         bool cand = valid && pd > 0;
@@ -362,7 +387,7 @@ __device__ inline void est_finish(Ctrl &c, unsigned long long S, uint32_t C, int
 
 __global__ void __launch_bounds__(64)
 k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
-           int64_t leafStride)
+           int64_t leafStride, SkipBlocks sk)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
@@ -372,7 +397,7 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
     const uint32_t n = 1u << d;
     unsigned long long S = 0;
     uint32_t C = 0;
-    est_exact_chain(T, P, d, 0, n < EST_HEAD ? n : EST_HEAD, S, C, lane);
+    est_exact_chain(T, P, d, 0, n < EST_HEAD ? n : EST_HEAD, S, C, lane, sk, brick);
     if (lane == 0) {
         if (n <= EST_HEAD) est_finish(c, S, C, maxEpochs);
         else {
@@ -389,7 +414,7 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
 // pd > h, so under the hypothesis floor(S/(2C+1)) == Th node k counts  <=>  pd_k > min(Th, h_k).
 __global__ void __launch_bounds__(256)
 k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
-           int64_t leafStride, uint32_t *__restrict__ summ, int64_t summStride)
+           int64_t leafStride, uint32_t *__restrict__ summ, int64_t summStride, SkipBlocks sk)
 {
     const int brick = blockIdx.y, lane = threadIdx.x & 63;
     const Ctrl &c = ctrls[brick];
@@ -405,13 +430,21 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     // what bounds this kernel: twice the bytes in flight per wave)
     uint4 tvN = make_uint4(0, 0, 0, 0);
     uint2 pvN = make_uint2(0, 0);
-    if (seg0 < nseg) { tvN = *(const uint4 *)(Tl + (size_t)seg0 * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)seg0 * (EST_SEG / 2)); }
+    bool skipN = seg0 < nseg && skip_block(sk, brick, d, seg0 * EST_SEG);       // a segment inside a skipped block: all zero, unread
+    if (seg0 < nseg && !skipN) { tvN = *(const uint4 *)(Tl + (size_t)seg0 * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)seg0 * (EST_SEG / 2)); }
     for (uint32_t seg = seg0; seg < nseg; seg += gridDim.x * 4) {
     const uint4 tv = tvN;
     const uint2 pv = pvN;
+    const bool skipped = skipN;
     {
         const uint32_t sn = seg + gridDim.x * 4;
-        if (sn < nseg) { tvN = *(const uint4 *)(Tl + (size_t)sn * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)sn * (EST_SEG / 2)); }
+        skipN = sn < nseg && skip_block(sk, brick, d, sn * EST_SEG);
+        if (sn < nseg && !skipN) { tvN = *(const uint4 *)(Tl + (size_t)sn * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)sn * (EST_SEG / 2)); }
+    }
+    if (skipped) {
+        uint32_t *outz = summ + (int64_t)brick * summStride * (4 * EST_CAND);
+        if (lane < 4 * nc) outz[est_at(lane >> 2, seg) + (lane & 3)] = 0;
+        continue;
     }
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w};
     vr_s16x2 pd[8], h[8];
@@ -472,7 +505,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
 
 __global__ void __launch_bounds__(64)
 k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride, ReconBufs rb,
-           int64_t leafStride, const uint32_t *__restrict__ summ, int64_t summStride)
+           int64_t leafStride, const uint32_t *__restrict__ summ, int64_t summStride, SkipBlocks sk)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
@@ -502,7 +535,7 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
                 }
                 return;
             }
-            est_exact_chain(T, P, d, seg * EST_SEG, n, S, C, lane);   // last resort: walk the rest in order
+            est_exact_chain(T, P, d, seg * EST_SEG, n, S, C, lane, sk, brick);   // last resort: walk the rest in order
             fallbacks += (int)(nseg - seg);
             break;
         }
@@ -538,7 +571,7 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
         S += lane_u32(si - ss, f);
         C += lane_u32(sci - sc, f);
         seg += f;
-        est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane);
+        est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane, sk, brick);
         Tc = (long long)(S / (2ull * C + 1ull));
         seg += 1;
         ++fallbacks;
@@ -622,7 +655,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 __global__ void __launch_bounds__(256)
 k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
-         int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+         int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk,
+         SkipBlocks sk)
 {
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
@@ -644,8 +678,11 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     // never read (VolumeKdtree.cpp:333 skips it outright), so the two extra evaluations are not made
     const bool needDF = cEpoch + 1 < maxEpochs;
     const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
-    const uint4 tv = *(const uint4 *)(T + i0);
-    const uint2 pv = *(const uint2 *)(P + (i0 >> 1));
+    // my wave's 1024 nodes inside a skipped block (SkipBlocks): no error, nothing to load, nothing anybody will read
+    const bool skipped = skip_block(sk, brick, d, (uint32_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) << 10);
+    uint4 tv = make_uint4(0, 0, 0, 0);
+    uint2 pv = make_uint2(0, 0);
+    if (!skipped) { tv = *(const uint4 *)(T + i0); pv = *(const uint2 *)(P + (i0 >> 1)); }
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
     const uint32_t d2 = (uint32_t)dist * 0x10001u, dm2 = (uint32_t)distM * 0x10001u, dp2 = (uint32_t)distP * 0x10001u;
     uint32_t e0 = 0, em = 0, ep = 0, wa = 0, wb = 0, rw[4] = {tw[0], tw[1], tw[2], tw[3]}, rprev = 0;
@@ -653,7 +690,13 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     // every code is "keep", the reconstruction is the truth, the error 0 at any distance (pd = 0 in encodeNode)
     const uint32_t differs = (tw[0] ^ __builtin_amdgcn_perm(0, pw[0], 0x01010000u)) | (tw[1] ^ __builtin_amdgcn_perm(0, pw[0], 0x03030202u)) |
                              (tw[2] ^ __builtin_amdgcn_perm(0, pw[1], 0x01010000u)) | (tw[3] ^ __builtin_amdgcn_perm(0, pw[1], 0x03030202u));
-    const bool busy = __ballot(differs != 0u) != 0ull;
+    const bool busy = !skipped && __ballot(differs != 0u) != 0ull;
+    // level D-2: my wave IS one 4096-leaf block's nodes of this level.  Constant block (k_pyramid12) and every truth
+    // equal to its parent's reconstruction: the two levels below need not be visited (SkipBlocks)
+    if (sk.flag && d == sk.Dm2 && !busy && (threadIdx.x & 63) == 0) {
+        uint8_t *f = sk.flag + (int64_t)brick * sk.nBlk + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (*f & 1u) *f = 3u;        // the same answer in every epoch of the level: it depends on truths and parents only
+    }
     if (busy)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {                        // sibling pair j: nodes 2j, 2j+1, parent byte j
@@ -673,8 +716,10 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     }
     // even nodes sit at bits 4j, odd ones at 16+4j: fold to 2 bits per node
     const uint32_t cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
-    *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
-    *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+    if (!skipped) {
+        *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
+        *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+    }
     // per-lane sums are < 2^21, a wave's < 2^27: 32-bit DPP scans, the total in lane 63
     unsigned long long s0 = 0, sm = 0, sp = 0;
     if (busy) {
@@ -1398,6 +1443,7 @@ struct PruneEmitArgs {
     ReconBufs rbR;
     uint8_t *gap, *gapR;           // the streams' block-gapped buffers (Stream2::tree)
     int64_t treeCap;
+    SkipBlocks sk;                 // blocks the level loop left alone below depth D-2: all "keep", exactly reproduced
 };
 
 __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
@@ -1441,11 +1487,18 @@ k_prune_emit12(PruneEmitArgs a)
     const int64_t n4 = ((int64_t)1 << (D - 4)) + (base >> 4) + t, n3 = ((int64_t)1 << (D - 3)) + (base >> 3) + 2 * t;
     const int64_t n2 = ((int64_t)1 << (D - 2)) + (base >> 2) + 4 * t, n1 = ((int64_t)1 << (D - 1)) + (base >> 1) + 8 * t;
     const uint32_t c4B = Cb[n4 >> 2], c3B = Cb[n3 >> 2], c2B = Cb[n2 >> 2];
-    const uint32_t c1H = *(const uint16_t *)(Cb + (n1 >> 2));
     const int64_t li = ((int64_t)1 << D) + base + t * 16;
-    const uint32_t cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
-    const uint4 tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
-    const uint4 rv = *(const uint4 *)((cPar == 0 ? a.rb.b[0] : (cPar == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+    // a block the level loop skipped (SkipBlocks) has no codes and no reconstruction in memory at depths D-1 and D:
+    // they are all "keep" and exact, which is what zeros here say
+    const bool skipB = a.sk.flag && (a.sk.flag[(int64_t)brick * a.sk.nBlk + blk] & 2u) != 0u;
+    uint32_t c1H = 0, cpk = 0;
+    uint4 tv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
+    if (!skipB) {
+        c1H = *(const uint16_t *)(Cb + (n1 >> 2));
+        cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
+        tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
+        rv = *(const uint4 *)((cPar == 0 ? a.rb.b[0] : (cPar == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+    }
     // RANGE: the same pieces of the range stream
     uint8_t *CbR = RANGE ? a.codesR + (int64_t)brick * a.codeStride : nullptr;
     uint32_t upBR = 0, c4BR = 0, c3BR = 0, c2BR = 0, c1HR = 0, cpkR = 0;
@@ -2344,7 +2397,7 @@ k_const_finish(int D, Ctrl *ctrls, uint8_t *tree, int64_t treeCap, uint32_t *idx
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint8_t *rootMin, const uint8_t *rootMax,
-                            int64_t mmStride)
+                            int64_t mmStride, SkipBlocks sk)
 {
     const int D = bs->D, B = bs->B;
     ReconBufs rb{{s.recon[0], s.recon[1], s.recon[2]}};
@@ -2357,23 +2410,23 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint
     for (int d = 0; d <= D; ++d) {
         const int64_t n = (int64_t)1 << d;
         hipLaunchKernelGGL(k_est_head, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride, rb,
-                           bs->leafStride);
+                           bs->leafStride, sk);
         if (n > EST_HEAD) {
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
             for (int r = 0; r < EST_ROUNDS; ++r) {
                 const int nc = r < 2 ? 4 : EST_CAND, ncNext = r + 1 < 2 ? 4 : EST_CAND;   // two 4-wide windows, then 8-wide ones
                 const unsigned gx = r == 0 ? cdiv(nseg, 16) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);   // four segments per wave first
                 hipLaunchKernelGGL(k_est_summ, dim3(gx, B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
-                                   bs->heapStride, rb, bs->leafStride, (uint32_t *)bs->estSumm, bs->estSummStride);
+                                   bs->heapStride, rb, bs->leafStride, (uint32_t *)bs->estSumm, bs->estSummStride, sk);
                 hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, ncNext,
                                    r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
-                                   (const uint32_t *)bs->estSumm, bs->estSummStride);
+                                   (const uint32_t *)bs->estSumm, bs->estSummStride, sk);
             }
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
                 hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, bs->maxEpochs, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk, sk);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
                                    s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
@@ -2447,6 +2500,10 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     const bool mr = bs->variant == 2;
     hipEventRecord(bs->ev[0], st);
     const uint8_t *rootMinP = nullptr, *rootMaxP = nullptr;   // where the last pyramid round leaves each brick's root (min,max)
+    const bool fused = D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
+    // SkipBlocks needs k_pyramid12's constant bit in front and k_prune_emit12 behind, a prune that makes such blocks
+    // one token (tolerance >= 1) and a level loop that runs
+    bool skipOn = fused && !mr && bs->blockFlag && bs->tolerance >= 1 && bs->maxEpochs >= 1 && D >= 14 && !getenv("VRHIP_NO_SKIP_BLOCKS");
     const int64_t rootStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
     // ---- BUILD: pyramid.  Bottom 12 levels by k_pyramid12 when x-runs of 16 voxels exist,
     // the rest (and small / thin bricks) in rounds of <= 10 levels.
@@ -2457,12 +2514,14 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         const int64_t oStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
         Pyr12Geom pg{};
         bool use12 = D >= 12 && !bs->generalGeom;
+        skipOn = skipOn && use12;
         if (use12) {
             for (int q = 0; q < 12; ++q) {
                 const int ax = bs->g.axis[D - 12 + q];
                 if (ax == 0) pg.ax++; else if (ax == 1) pg.ay++; else pg.az++;
             }
             use12 = pg.ax >= 4;
+            skipOn = skipOn && use12;
             for (int i = 0; i < 16 && use12; ++i) {
                 uint32_t r = 0;
                 for (int q = 0; q < 12; ++q) {
@@ -2481,7 +2540,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
             pg.spread = bs->spread;
             hipLaunchKernelGGL(k_pyramid12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, bs->g, pg, vox,
                                bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr, bs->mmMin[0], bs->mmMax[0],
-                               oStride);
+                               oStride, skipOn ? bs->blockFlag : nullptr);
             dLeaf = D - 12;
             inMin = bs->mmMin[0]; inMax = bs->mmMax[0]; inStride = oStride;
             rootMinP = inMin; rootMaxP = inMax;
@@ -2511,8 +2570,9 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // ---- COMPRESS
     // constant bricks take the closed form (VolumeKdtree streams; needs the leaf prune and an epoch to exist)
     const bool constOk = !mr && bs->maxEpochs >= 1 && bs->tolerance >= 1 && D >= 1;
-    compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride);
-    if (mr) compress_stream(bs, bs->rng, st, nullptr, nullptr, 0);
+    const SkipBlocks sk{skipOn ? bs->blockFlag : nullptr, (int64_t)1 << (D >= 12 ? D - 12 : 0), D - 2};
+    compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk);
+    if (mr) compress_stream(bs, bs->rng, st, nullptr, nullptr, 0, SkipBlocks{nullptr, 0, 0});
     hipEventRecord(bs->ev[2], st);
     dbg_sync(st, "compress");
     // ---- PRUNE
@@ -2521,9 +2581,9 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     ReconBufs rbR{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     int pruneFrom = D - 1;
     bs->fineHas.assign((size_t)B, 0);
-    const bool fused = D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
     if (fused) {
         PruneEmitArgs pa;
+        pa.sk = sk;
         pa.D = D; pa.tol = bs->tolerance; pa.maxDepth = bs->maxDepth; pa.ctrls = bs->mid.ctrl;
         pa.temp = bs->mid.temp; pa.codes = bs->mid.codes;
         pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->leafStride;
