@@ -76,7 +76,8 @@ typedef struct vr_tree_info {
                                   * of zeros to 3s (R.cpp:662-669,686-688).  Provably impossible for tolerance >= 0, so
                                   * the GPU emitters count instead of rewriting; anything but 0 here means the stream
                                   * differs from the reference's */
-    int32_t reserved;
+    int32_t est_exact_segments;  /* diagnostic: 1024-node segments the distance estimator (R.cpp:415-455) had to walk node by
+                                  * node instead of taking from their summaries; 0 for opened / set trees */
 } vr_tree_info;
 
 /* ---- library / device ------------------------------------------------------- */

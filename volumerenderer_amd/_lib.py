@@ -27,7 +27,7 @@ class TreeInfo(C.Structure):
                 ("num_active_nodes", C.c_int64), ("tree_bytes", C.c_int64),
                 ("tolerance", C.c_int32), ("max_epochs", C.c_int32), ("variant", C.c_int32),
                 ("num_reverts", C.c_int32), ("max_error_before", C.c_int32), ("max_error_after", C.c_int32),
-                ("mean_l1_after", C.c_double), ("zero_run_rewrites", C.c_int32), ("reserved", C.c_int32)]
+                ("mean_l1_after", C.c_double), ("zero_run_rewrites", C.c_int32), ("est_exact_segments", C.c_int32)]
 
 
 class Camera(C.Structure):

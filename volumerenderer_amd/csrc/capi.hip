@@ -351,6 +351,7 @@ vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
     info->max_error_after = c.maxErrAfter;
     info->mean_l1_after = (double)c.statL1 / (double)b.leafStride;
     info->zero_run_rewrites = c.constBrick ? 0 : c.zeroRun + (int32_t)b.lutZeroRun;
+    info->est_exact_segments = c.constBrick ? 0 : c.estFallbacks;
     return VR_OK;
 }
 

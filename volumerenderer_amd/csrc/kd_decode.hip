@@ -268,6 +268,7 @@ struct TileArgs {
     const uint8_t *fine;        // BrickSet::fineIdx (k_decode_fine only)
     const uint32_t *tables;     // BrickSet::decTables (k_decode_fine) / BrickSet::chainTab (k_decode_quad)
     const uint8_t *val3;        // BrickSet::idxVal3 (k_decode_quad only)
+    uint8_t kqBit[8];           // k_decode_quad: bit i of a workgroup's ticket number = this bit of the tile's number
 };
 
 #define DEC_WAVES 4
@@ -401,6 +402,24 @@ __device__ __forceinline__ void tile_fill_dead(const TileArgs &a, const uint32_t
                  (int64_t)a.g.X * ((int64_t)ty * 8 + y + (int64_t)a.g.Y * ((int64_t)tz * 4));
     const int64_t zs = (int64_t)a.g.X * a.g.Y;
     const uint4 v = *(const uint4 *)(tile + 4 * c + 32 * (y >> 2));
+#if QD_EXP == 5      // timing experiment: 256-byte runs (rows of a 256-wide brick), 4 rows per store
+    {
+        const int64_t lin = (int64_t)tx + a.tilesX * ((int64_t)ty + (int64_t)a.tilesY * tz);      // tile number
+        uint8_t *L = a.out + (int64_t)brick * a.g.voxels + (lin >> 1) * 8192 + (lin & 1) * 1024 + lane * 16;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) *(uint4 *)(L + 2048 * z) = v;
+        return;
+    }
+#endif
+#if QD_EXP == 6      // timing experiment: 4 KB contiguous per tile
+    {
+        const int64_t lin = (int64_t)tx + a.tilesX * ((int64_t)ty + (int64_t)a.tilesY * tz);
+        uint8_t *L = a.out + (int64_t)brick * a.g.voxels + lin * 4096 + lane * 16;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) *(uint4 *)(L + 1024 * z) = v;
+        return;
+    }
+#endif
 #pragma unroll
     for (int z = 0; z < 4; ++z) *(uint4 *)(O + zs * z) = v;
 }
@@ -892,39 +911,45 @@ __device__ __forceinline__ uint32_t ones_from(uint32_t f, uint32_t x)
     return r;
 }
 
-struct QuadDist { int d4, d5, d6; };     // distances of depths D-2, D-1, D (0 below a progressive cut)
-
 // one voxel leaf: yl = the 16 bits that start at its code.  Returns the voxel; e = bits before its last token
 // (the leaf takes e + 2 bits: code + branch tokens up to and including the terminator, at most 8 tokens)
-__device__ __forceinline__ int qd_leaf(uint32_t yl, int V5, int d6, const uint32_t *chainS, uint32_t &e)
+// The three tree levels of a quad move a scalar by 0 / +distance / -distance / 0 for the token 0 / 1 / 2 / 3
+// (R.cpp:783-787): four words per level in LDS (QuadDelta), read with the token as the address -- on gfx950 the
+// arithmetic form (v_bfe_i32, add, shift, v_mad_i32_i24) costs 14 cycles of the SIMD per node, two plain
+// instructions and an LDS read that nothing waits for cost 5.
+struct QuadDelta { int d4[4], d5[4], d6[4]; };
+
+__device__ __forceinline__ int qd_leaf(uint32_t yl, int V5, const int *delta6, const uint32_t *chainS, uint32_t &e)
 {
     const uint32_t T = yl & (yl >> 1) & 0x5555u;            // bit 2i <=> token i is '3' (i = 0: the code, a pruned leaf)
     const uint32_t f = ffbl_u32(T);
     e = min(f, 14u);
-    const int sc = __builtin_amdgcn_sbfe((int)yl, 0, 2);    // code 1 -> +1, 2 -> -2, 3 -> -1
-    const int Vc = med3i(mad24i((sc + 1) >> 1, d6, V5), 0, 255);           // R.cpp:783-787
+    const int dl = *(const int *)((const char *)delta6 + ((yl & 3u) << 2));
     const uint32_t ym = ones_from(f, yl);                   // the tokens from the first '3' on read as '3'
     // branch tokens = bits 2..15.  (Measured on gfx950: a two-operand VALU instruction takes 2 cycles of the SIMD,
     // a three-operand or byte-select (SDWA) one 4 -- scratch/mb/valu_rate.hip -- so the three byte selects below cost
     // what six plain instructions would; reading the entry's bytes with three LDS reads instead was 27 % slower.)
     const uint32_t ent = *(const uint32_t *)((const char *)chainS + (ym & QD_KEYMASK));
-    int v = Vc + (int)(int8_t)(ent & 255u);
+    // The leaf's own step clamps to [0, 255] (R.cpp:783-787) before the branch's composed clamp-add f runs; f is
+    // monotone with f(0) = LO and f(255) = HI, and f(v) = min(max(v + A, LO), HI) on [0, 255], so
+    // f(clamp(x, 0, 255)) = min(max(x + A, LO), HI) for every x: the inner clamp needs no instruction.
+    int v = V5 + dl + (int)(int8_t)(ent & 255u);
     v = min(max(v, (int)((ent >> 16) & 255u)), (int)(ent >> 24));
     return v;
 }
 
 // a depth-(D-1) node and its two leaves: y = the 32 bits that start at the node's token, yh the 32 after them.
-// Returns the two voxels (bytes 0, 1); used = bits the pair takes.
-__device__ __forceinline__ uint32_t qd_pair(uint32_t y, uint32_t yh, bool dead, int Vp, const QuadDist &qd,
+// dead3 = 3 where an ancestor is pruned (the node then reads as pruned), else 0.  Returns the two voxels (bytes 0, 1);
+// used = bits the pair takes.
+__device__ __forceinline__ uint32_t qd_pair(uint32_t y, uint32_t yh, uint32_t dead3, int Vp, const QuadDelta *qd,
                                             const uint32_t *chainS, uint32_t &used)
 {
-    int s5 = __builtin_amdgcn_sbfe((int)y, 0, 2);
-    s5 = dead ? -1 : s5;
-    const int V5 = med3i(mad24i((s5 + 1) >> 1, qd.d5, Vp), 0, 255);
-    const bool pr = s5 == -1;                               // pruned (or under a pruned node): both voxels = Vp
+    const uint32_t c5 = (y & 3u) | dead3;
+    const int V5 = med3i(Vp + *(const int *)((const char *)qd->d5 + (c5 << 2)), 0, 255);
+    const bool pr = c5 == 3u;                               // pruned (or under a pruned node): both voxels = Vp
     uint32_t e1, e2;
-    int v1 = qd_leaf(y >> 2, V5, qd.d6, chainS, e1);
-    int v2 = qd_leaf(__builtin_amdgcn_alignbit(yh, y, e1 + 4u), V5, qd.d6, chainS, e2);
+    int v1 = qd_leaf(y >> 2, V5, qd->d6, chainS, e1);
+    int v2 = qd_leaf(__builtin_amdgcn_alignbit(yh, y, e1 + 4u), V5, qd->d6, chainS, e2);
     v1 = pr ? Vp : v1;
     v2 = pr ? Vp : v2;
     used = pr ? 2u : e1 + e2 + 6u;
@@ -942,6 +967,9 @@ k_decode_quad(TileArgs a)
         uint32_t chain[QD_CHAIN_ENTRIES];
         uint32_t tile[QD_WAVES][16 * QD_TS];    // [leaf / 4][block of the tile]
         uint32_t off[QD_WAVES][64];             // per block of the tile: token offset of its root
+        unsigned long long live[QD_WAVES * QD_TPW];   // per tile of the workgroup: which of its 64 blocks have a live root
+        uint8_t val[QD_WAVES * QD_TPW][64];     // ... and the scalars of their roots (all a dead tile needs)
+        QuadDelta delta;                        // 0 / +d / -d / 0 per token for depths D-2, D-1, D
         int next;                               // next tile of the workgroup nobody has taken yet
     };
     __shared__ __attribute__((aligned(16))) Shared sm;
@@ -952,19 +980,52 @@ k_decode_quad(TileArgs a)
     const int ntiles = a.tilesX * a.tilesY * a.tilesZ;
     const int tile0 = blockIdx.x * (QD_WAVES * QD_TPW);               // the workgroup's tiles: tile0 .. tile0 + 16 * QD_TPW - 1
     uint32_t *tile = sm.tile[wave];
-    // ---- does anybody here need the table?  (index offsets of all the workgroup's tiles, QD_TPW per thread)
-    bool any = false;
+    // ---- which tile a ticket stands for.  A tile is 128 x 8 x 4 voxels (whole 128-byte lines per row); the strings it
+    // reads belong to eight 16 x 16 x 16 emit blocks, each shared with the seven other tiles of the same 16 x 16 (y, z)
+    // cell.  Tickets are numbered so that those eight tiles are consecutive: the workgroup's waves read an emit block's
+    // string while its lines are still in the CU's cache, instead of fetching every line from HBM up to eight times
+    // (tile numbers in address order did: 11.3 GB fetched for 4.5 GB of stream and 2 GB of side-cars).
+    static_assert(QD_WAVES * QD_TPW == 256, "ticket numbers are permuted as 8-bit numbers");
+    const auto tile_of = [&](int kq) {
+        int t = 0;
 #pragma unroll
-    for (int k = 0; k < QD_TPW; ++k) {
-        const int tileId = tile0 + wave * QD_TPW + k;
-        if (tileId < ntiles) {
-            const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
-            const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
-            const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
-            any = any || a.idxOff[(int64_t)brick * a.nIdx + s] != VR_IDX_DEAD;
+        for (int i = 0; i < 8; ++i) t |= ((kq >> i) & 1) << a.kqBit[i];
+        return t;
+    };
+    // ---- index pre-pass: the root offsets and scalars of all the workgroup's blocks, QD_TPW tiles per wave, as
+    // independent loads (one memory round trip for the lot).  A tile under pruned nodes then costs its wave no global
+    // load at all -- its per-tile chain spread table -> index -> stores was latency, not bandwidth: a volume of
+    // constant blocks decoded at 2 TB/s -- and the table is copied only if some tile needs it.
+    bool any = false;
+    {
+        uint32_t offP[QD_TPW], valP[QD_TPW];
+#pragma unroll
+        for (int k = 0; k < QD_TPW; ++k) {
+            const int tileId = tile0 + tile_of(wave * QD_TPW + k);
+            offP[k] = VR_IDX_DEAD; valP[k] = 0;
+            if (tileId < ntiles) {
+                const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
+                const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
+                const uint32_t s = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
+                offP[k] = a.idxOff[(int64_t)brick * a.nIdx + s];
+                valP[k] = a.idxVal[(int64_t)brick * a.nIdx + s];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QD_TPW; ++k) {
+            const unsigned long long m = __ballot(offP[k] != VR_IDX_DEAD);
+            if (lane == 0) sm.live[wave * QD_TPW + k] = m;
+            sm.val[wave * QD_TPW + k][lane] = (uint8_t)valP[k];
+            any = any || m != 0ull;
         }
     }
     if (threadIdx.x == 0) sm.next = 0;
+    if (threadIdx.x < 12) {         // distances of depths D-2, D-1, D (0 below a progressive cut)
+        const uint8_t *dmap = a.ctrls[brick].distanceMap;
+        const int lv = threadIdx.x >> 2, tok = threadIdx.x & 3, depth = a.D - 2 + lv;
+        const int dist = depth <= a.cut ? dmap[depth] : 0;
+        (&sm.delta.d4[0])[threadIdx.x] = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+    }
     if (__syncthreads_or(any ? 1 : 0)) {
         const uint4 *src = (const uint4 *)a.tables;
         uint4 *dst = (uint4 *)chainS;
@@ -972,32 +1033,49 @@ k_decode_quad(TileArgs a)
         for (int i = 0; i < QD_CHAIN_ENTRIES / 4 / (64 * QD_WAVES); ++i) dst[i * 64 * QD_WAVES + threadIdx.x] = src[i * 64 * QD_WAVES + threadIdx.x];
         __syncthreads();
     }
-    QuadDist qd;
-    {
-        const uint8_t *dmap = a.ctrls[brick].distanceMap;
-        qd.d4 = a.D - 2 <= a.cut ? dmap[a.D - 2] : 0;
-        qd.d5 = a.D - 1 <= a.cut ? dmap[a.D - 1] : 0;
-        qd.d6 = a.D <= a.cut ? dmap[a.D] : 0;
-    }
+    const QuadDelta *qd = &sm.delta;
     const int g = lane & 15;
     const uint32_t ownN = g == 0 ? 4u : (uint32_t)(__ffs(g) - 1);     // ancestors (depth >= Ds) whose tokens head my run
     const uint32_t p0 = 2u * ownN, p1 = p0 + 2u;                       // bit of my root's token / of my first pair's
     const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
     // ---- the waves take the workgroup's tiles from a counter: tiles in pruned regions cost a fraction of a detailed
-    // one, and with the table only one workgroup fits a CU, so a fixed split would leave SIMDs idle behind the slowest wave
-    while (true) {
+    // one, and with the table only one workgroup fits a CU, so a fixed split would leave SIMDs idle behind the slowest wave.
+    // A wave holds TWO tickets: while it decodes one tile, the index data of its next one (root offsets, side-car counts,
+    // depth-(D-3) scalars) is already on its way -- with four waves per SIMD nothing else hides that round trip, and a
+    // tile's loads (index -> side-cars -> stream words) were twice its arithmetic.
+    // rank of my block inside a tile, and the tile's own part, which is wave-uniform (the spread table is bitwise linear)
+    const uint32_t spreadLane = a.spread[4 * (lane & 31)] | a.spread[a.g.X + 4 * (lane >> 5)];
+    struct Ticket { int kq; unsigned long long liveMask; uint32_t off, val0; uint4 cv; uint2 sv; };
+    const auto take = [&](Ticket &t) {
         int kq = 0;
         if (lane == 0) kq = atomicAdd(&sm.next, 1);
         kq = __builtin_amdgcn_readfirstlane(kq);
-        const int tileId = tile0 + kq;
-        if (kq >= QD_WAVES * QD_TPW || tileId >= ntiles) break;       // wave-uniform
+        t.kq = kq >= QD_WAVES * QD_TPW ? -1 : kq;       // wave-uniform
+        t.liveMask = 0ull; t.off = VR_IDX_DEAD; t.val0 = 0;
+        t.cv = make_uint4(0, 0, 0, 0); t.sv = make_uint2(0, 0);
+        if (t.kq < 0) return;
+        t.liveMask = sm.live[kq];
+        t.val0 = sm.val[kq][lane];
+        if (t.liveMask != 0ull && ((t.liveMask >> lane) & 1ull)) {
+            const int tileId = tile0 + tile_of(kq);
+            const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
+            const uint32_t spreadTile = a.spread[128 * tx] | a.spread[a.g.X + 8 * ty] | a.spread[a.g.X + a.g.Y + 4 * tz];
+            const int64_t io = (int64_t)brick * a.nIdx + ((spreadLane | spreadTile) >> 6);
+            t.off = a.idxOff[io];          // (cached: the pre-pass has just read it; live <=> not VR_IDX_DEAD)
+            t.cv = *(const uint4 *)(a.fine + io * 16);
+            t.sv = *(const uint2 *)(a.val3 + io * 8);
+        }
+    };
+    Ticket nxt;
+    take(nxt);
+    while (nxt.kq >= 0) {
+        const Ticket cur = nxt;
+        take(nxt);
+        const int tileId = tile0 + tile_of(cur.kq);
+        if (tileId >= ntiles) continue;       // (a last, partial group: wave-uniform)
         const int tx = tileId & (a.tilesX - 1), ty = (tileId >> a.ltx) & (a.tilesY - 1), tz = tileId >> (a.ltx + a.lty);
-        const int sc[3] = {tx * 32 + (lane & 31), ty * 2 + (lane >> 5), tz};
-        const uint32_t sB = (a.spread[4 * sc[0]] | a.spread[a.g.X + 4 * sc[1]] | a.spread[a.g.X + a.g.Y + 4 * sc[2]]) >> 6;
-        const int64_t io = (int64_t)brick * a.nIdx + sB;
-        const uint32_t off = a.idxOff[io];
-        const uint32_t val0 = a.idxVal[io];
-        const unsigned long long liveMask = __ballot(off != VR_IDX_DEAD);
+        const unsigned long long liveMask = cur.liveMask;
+        const uint32_t off = cur.off, val0 = cur.val0;
         if (liveMask == 0ull) tile[lane] = val0 * 0x01010101u;          // as in k_decode_tile: one value per block
         else {
             // ---- park, for each 4-leaf subtree of my block: the scalar of its depth-(D-3) parent (bits 0-7), the token
@@ -1006,12 +1084,8 @@ k_decode_quad(TileArgs a)
             // run -- a pruned ancestor ends the run).  A block under a pruned node parks "no root" with offset 0 at the
             // stream's first word, or, where its whole step is skipped, the final words.
             const bool deadB = off == VR_IDX_DEAD;
-            uint4 cv = make_uint4(0, 0, 0, 0);
-            uint2 sv = make_uint2(0, 0);
-            if (!deadB) {
-                cv = *(const uint4 *)(a.fine + io * 16);
-                sv = *(const uint2 *)(a.val3 + io * 8);
-            }
+            const uint4 cv = cur.cv;
+            const uint2 sv = cur.sv;
             offS[wave][lane] = deadB ? 0u : off;
             const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, sw[2] = {sv.x, sv.y};
             const uint32_t rep = val0 * 0x01010101u;
@@ -1054,17 +1128,16 @@ k_decode_quad(TileArgs a)
                 const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
                                hh = __builtin_amdgcn_alignbit(w3, w2, b);
                 // my depth-(D-2) root (behind the ancestors' tokens)
-                int s4 = __builtin_amdgcn_sbfe((int)lo, p0, 2);
-                s4 = live ? s4 : -1;
-                const int V4 = med3i(mad24i((s4 + 1) >> 1, qd.d4, V3), 0, 255);
-                const bool dead = s4 == -1;
+                const uint32_t c4 = live ? __builtin_amdgcn_ubfe(lo, p0, 2) : 3u;
+                const int V4 = med3i(V3 + *(const int *)((const char *)qd->d4 + (c4 << 2)), 0, 255);
+                const uint32_t dead3 = c4 == 3u ? 3u : 0u;
                 uint32_t used1, used2;
-                const uint32_t b01 = qd_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead, V4,
+                const uint32_t b01 = qd_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead3, V4,
                                              qd, chainS, used1);
                 const uint32_t p2 = p1 + used1;                   // <= 10 + 34
                 const bool q = p2 >= 32u;
                 const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
-                const uint32_t b23 = qd_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead, V4,
+                const uint32_t b23 = qd_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead3, V4,
                                              qd, chainS, used2);
                 return b01 | (b23 << 16);
             };
@@ -1130,6 +1203,18 @@ static bool tile_geometry(const BrickSet *bs, TileArgs &a)
     a.ltx = 0; while ((1 << a.ltx) < a.tilesX) ++a.ltx;
     a.lty = 0; while ((1 << a.lty) < a.tilesY) ++a.lty;
     if ((1 << a.ltx) != a.tilesX || (1 << a.lty) != a.tilesY) return false;
+    // ticket order inside a group of 256 tiles (k_decode_quad): first the bits that stay inside a 16 x 16 (y, z) cell --
+    // z bits 0-1 and y bit 0 of the tile coordinate -- then the others in address order
+    {
+        const int first[3] = {a.ltx + a.lty, a.ltx + a.lty + 1, a.ltx};
+        int n = 0;
+        bool used[8] = {false, false, false, false, false, false, false, false};
+        for (int i = 0; i < 3; ++i) {
+            const bool exists = i < 2 ? (1 << (i + 1)) <= a.tilesZ : a.tilesY >= 2;
+            if (exists && first[i] < 8 && !used[first[i]]) { a.kqBit[n++] = (uint8_t)first[i]; used[first[i]] = true; }
+        }
+        for (int b = 0; b < 8; ++b) if (!used[b]) a.kqBit[n++] = (uint8_t)b;
+    }
     return true;
 }
 

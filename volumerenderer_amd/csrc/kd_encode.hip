@@ -97,7 +97,7 @@ struct Pyr12Geom {
     int ax, ay, az; uint16_t sx[16];   // sx[i]: Morton rank bits of x = i (low 4 x bits)
     // XCD-aware block order (swz != 0): the eight 16-voxel-wide boxes that share every 128-byte line of an
     // x-run go to the same XCD (workgroup id mod 8) back to back, so that XCD's L2 fetches each line once
-    int swz, nbx, nby;
+    int swz, nbx, nby, lnbx, lnby;     // lnbx, lnby = log2
     const uint32_t *spread;            // BrickSet::spread
 };
 
@@ -122,15 +122,17 @@ k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__re
     __shared__ uint32_t waveMM[4];
     const int brick = blockIdx.y, D = g.D;
     // which 2^ax x 2^ay x 2^az box: enumerated by box coordinates (x fastest), not by Morton index
+    // (nbx, nby are powers of two -- the extents are -- so the box coordinates come from shifts and masks: the three
+    // 32-bit divisions they replaced were ~200 scalar instructions in front of every wave's first load)
     uint32_t bid = blockIdx.x;
     if (pg.swz) {
         const uint32_t slot = bid >> 3;
         const uint32_t grp = (slot >> 3) * 8u + (bid & 7u), m = slot & 7u;       // group -> XCD grp % 8, members in a row
-        const uint32_t ngx = (uint32_t)pg.nbx >> 3;
-        bid = (grp / ngx) * (uint32_t)pg.nbx + (grp % ngx) * 8u + m;
+        const int lgx = pg.lnbx - 3;                                              // log2(nbx / 8)
+        bid = ((grp >> lgx) << pg.lnbx) + ((grp & ((1u << lgx) - 1u)) << 3) + m;
     }
-    const int bx = (int)((bid % (uint32_t)pg.nbx) << pg.ax), by = (int)(((bid / (uint32_t)pg.nbx) % (uint32_t)pg.nby) << pg.ay),
-              bz = (int)((bid / ((uint32_t)pg.nbx * (uint32_t)pg.nby)) << pg.az);
+    const int bx = (int)((bid & ((1u << pg.lnbx) - 1u)) << pg.ax), by = (int)(((bid >> pg.lnbx) & ((1u << pg.lnby) - 1u)) << pg.ay),
+              bz = (int)((bid >> (pg.lnbx + pg.lnby)) << pg.az);
     const uint32_t *sp = pg.spread;
     const uint32_t base = sp[bx] | sp[g.X + by] | sp[g.X + g.Y + bz];           // Morton rank of the box origin
     uint8_t *T = temp + (int64_t)brick * heapStride;
@@ -2277,7 +2279,10 @@ k_index12(EmitArgs a)
         val = (D - 12 + q) == 0 ? val : apply_code(val, code, dist[q]);
     }
     // (64-bit trees: the entry stays relative to the block, whose slot offset goes to idxBase)
-    a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD) ? (a.idxBase ? 0u : blk * (uint32_t)PE_TOKENS) + local : VR_IDX_DEAD;
+    // an entry whose own token is a 3 is as good as one under a pruned node: all its voxels take its scalar, and a
+    // decoder that sees "dead" fills them without touching the stream
+    const bool root3 = ((cb[6] >> csh[6]) & 3u) == 3u;
+    a.idxOff[io] = ((bflags & 2) && local != VR_IDX_DEAD && !root3) ? (a.idxBase ? 0u : blk * (uint32_t)PE_TOKENS) + local : VR_IDX_DEAD;
     if (a.idxBase && t == 0) a.idxBase[bo] = (unsigned long long)blk * PE_TOKENS;
     a.idxVal[io] = (uint8_t)val;
     uint32_t lo3 = 0, hi3 = 0;
@@ -2537,6 +2542,8 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
             const int64_t perLine = (bs->g.X < 128 ? bs->g.X : 128) >> pg.ax;
             pg.swz = (perLine == 8 && Bx % 8 == 0 && ((Bx / 8) * By * Bz) % 8 == 0 && !getenv("VRHIP_NOSWZ")) ? 1 : 0;
             pg.nbx = (int)Bx; pg.nby = (int)By;
+            pg.lnbx = 0; while ((1 << pg.lnbx) < pg.nbx) ++pg.lnbx;
+            pg.lnby = 0; while ((1 << pg.lnby) < pg.nby) ++pg.lnby;
             pg.spread = bs->spread;
             hipLaunchKernelGGL(k_pyramid12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, bs->g, pg, vox,
                                bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr, bs->mmMin[0], bs->mmMax[0],
