@@ -1,14 +1,17 @@
 """Turn the rocprofv3 outputs merged into gpurun_out/ (profiles/refresh_profiles.sh) into the committed profiles/r02_* files."""
 import csv, glob, json, collections, shutil, os
+def newest(pattern):
+    """gpurun merges into gpurun_out/ without deleting: take the latest run's file"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
 R = "/root/repo/gpurun_out"
 P = "/root/repo/profiles"
-st = glob.glob(R + "/r2_stats/*/*kernel_stats.csv")[0]
+st = newest(R + "/r2_stats/*/*kernel_stats.csv")
 shutil.copy(st, P + "/r02_bench_kernel_stats.csv")
 ss = glob.glob(R + "/r2_stats_serial/*/*kernel_stats.csv")
-if ss: shutil.copy(ss[0], P + "/r02_bench_serial_kernel_stats.csv")
+if ss: shutil.copy(newest(R + "/r2_stats_serial/*/*kernel_stats.csv"), P + "/r02_bench_serial_kernel_stats.csv")
 def pmc(d, name):
     acc = collections.defaultdict(list)
-    f = glob.glob(R + "/" + d + "/*/*counter_collection.csv")[0]
+    f = newest(R + "/" + d + "/*/*counter_collection.csv")
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name and "vr::" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
