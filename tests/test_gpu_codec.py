@@ -634,3 +634,29 @@ def test_64_bit_token_offsets_small(vr, oracle, shape, monkeypatch):
     assert np.array_equal(ms.tree(0), ref.tree) and np.array_equal(ms.tree_range(0), ref.tree_range)
     assert np.array_equal(ms.decode().cpu().numpy().reshape(shape), ref.levelCut())
     assert np.array_equal(ms.decode_range().cpu().numpy().reshape(shape), ref.levelCutRange(None))
+
+
+@pytest.mark.parametrize("tol,ep", [(1, 1), (1, 2), (2, 3), (4, 2)])
+def test_constant_blocks_skipped_by_the_level_loop(vr, oracle, monkeypatch, tol, ep):
+    """SkipBlocks (kd_encode.hip): 16x16x16 boxes of one value each -- some reproduced exactly by depth D-3 (their
+    neighbours hold the same value), most not -- next to noisy boxes.  The level loop leaves the exact ones alone at
+    depths D-1 and D; stream, distances and statistics must not notice (oracle), nor differ from a build with the
+    shortcut switched off."""
+    rng = np.random.default_rng(77 + tol * 10 + ep)
+    shape = (32, 64, 64)                  # D = 17: 32 blocks of 4096 leaves
+    z, y, x = shape
+    coarse = rng.integers(0, 256, (z // 16, y // 16, x // 16)).astype(np.uint8)
+    coarse[:, :2, :2] = 90                # a 32 x 32 region of equal boxes: exact early, skipped
+    coarse[0, 2:, 2:] = 255               # saturated boxes
+    vol = np.repeat(np.repeat(np.repeat(coarse, 16, 0), 16, 1), 16, 2)
+    noisy = rng.random((z // 16, y // 16, x // 16)) < 0.25
+    mask = np.repeat(np.repeat(np.repeat(noisy, 16, 0), 16, 1), 16, 2)
+    vol = np.where(mask, rng.integers(0, 256, shape), vol).astype(np.uint8)
+    ref, bs = check_case(vr, oracle, vol, tol, ep)
+    monkeypatch.setenv("VRHIP_NO_SKIP_BLOCKS", "1")
+    plain = vr.BrickSet(1, (x, y, z), tol, ep)
+    plain.build(vol.copy())
+    monkeypatch.delenv("VRHIP_NO_SKIP_BLOCKS")
+    assert np.array_equal(plain.tree(0), bs.tree(0))
+    assert list(plain.distance_map(0)) == list(bs.distance_map(0))
+    assert plain.info(0) == bs.info(0)
