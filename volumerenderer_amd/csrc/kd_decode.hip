@@ -353,6 +353,22 @@ __device__ __forceinline__ void tile_gather(const TileArgs &a, const uint32_t *t
 }
 
 
+#ifndef QD_NT
+#define QD_NT 1
+#endif
+// decoded voxels are written once and not read again by this launch: streaming stores keep them from displacing the
+// stream and side-car lines the neighbouring tiles are about to read
+__device__ __forceinline__ void store_out16(uint8_t *p, uint4 v)
+{
+#if QD_NT
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, (u32x4 *)p);
+#else
+    *(uint4 *)p = v;
+#endif
+}
+
 // the same gather with wide LDS reads (k_decode_quad).  A 16-byte row piece = the voxels x = 16c .. 16c+15 of one (y, z)
 // = the same leaf positions of four neighbouring blocks 4c .. 4c+3, whose tile words are consecutive: one ds_read_b128
 // per (dx bit 1 [, dx bit 0]) brings them all, v_perm picks the bytes.  y = lane >> 3 and z = the store's index.
@@ -374,8 +390,8 @@ __device__ __forceinline__ void tile_gather_wide(const TileArgs &a, const uint32
             const uint32_t sel = b0 | (b1 << 8) | ((4u + b0) << 16) | ((4u + b1) << 24);
             const uint32_t g0 = rb >> 2, g1 = g0 | (2u << jx);
             const uint4 A = *(const uint4 *)(col + g0 * stride), B = *(const uint4 *)(col + g1 * stride);
-            *(uint4 *)(O + zs * z) = make_uint4(__builtin_amdgcn_perm(B.x, A.x, sel), __builtin_amdgcn_perm(B.y, A.y, sel),
-                                                __builtin_amdgcn_perm(B.z, A.z, sel), __builtin_amdgcn_perm(B.w, A.w, sel));
+            store_out16(O + zs * z, make_uint4(__builtin_amdgcn_perm(B.x, A.x, sel), __builtin_amdgcn_perm(B.y, A.y, sel),
+                                               __builtin_amdgcn_perm(B.z, A.z, sel), __builtin_amdgcn_perm(B.w, A.w, sel)));
         }
     } else {                                                          // jx == 2: dx bit 0 is bit 0 of the word's row
 #pragma unroll
@@ -388,7 +404,7 @@ __device__ __forceinline__ void tile_gather_wide(const TileArgs &a, const uint32
             const auto mk = [sel](uint32_t w00, uint32_t w01, uint32_t w10, uint32_t w11) {
                 return __builtin_amdgcn_perm(__builtin_amdgcn_perm(w11, w10, sel), __builtin_amdgcn_perm(w01, w00, sel), 0x05040100u);
             };
-            *(uint4 *)(O + zs * z) = make_uint4(mk(A.x, B.x, C.x, E.x), mk(A.y, B.y, C.y, E.y), mk(A.z, B.z, C.z, E.z), mk(A.w, B.w, C.w, E.w));
+            store_out16(O + zs * z, make_uint4(mk(A.x, B.x, C.x, E.x), mk(A.y, B.y, C.y, E.y), mk(A.z, B.z, C.z, E.z), mk(A.w, B.w, C.w, E.w)));
         }
     }
 }
@@ -402,26 +418,8 @@ __device__ __forceinline__ void tile_fill_dead(const TileArgs &a, const uint32_t
                  (int64_t)a.g.X * ((int64_t)ty * 8 + y + (int64_t)a.g.Y * ((int64_t)tz * 4));
     const int64_t zs = (int64_t)a.g.X * a.g.Y;
     const uint4 v = *(const uint4 *)(tile + 4 * c + 32 * (y >> 2));
-#if QD_EXP == 5      // timing experiment: 256-byte runs (rows of a 256-wide brick), 4 rows per store
-    {
-        const int64_t lin = (int64_t)tx + a.tilesX * ((int64_t)ty + (int64_t)a.tilesY * tz);      // tile number
-        uint8_t *L = a.out + (int64_t)brick * a.g.voxels + (lin >> 1) * 8192 + (lin & 1) * 1024 + lane * 16;
 #pragma unroll
-        for (int z = 0; z < 4; ++z) *(uint4 *)(L + 2048 * z) = v;
-        return;
-    }
-#endif
-#if QD_EXP == 6      // timing experiment: 4 KB contiguous per tile
-    {
-        const int64_t lin = (int64_t)tx + a.tilesX * ((int64_t)ty + (int64_t)a.tilesY * tz);
-        uint8_t *L = a.out + (int64_t)brick * a.g.voxels + lin * 4096 + lane * 16;
-#pragma unroll
-        for (int z = 0; z < 4; ++z) *(uint4 *)(L + 1024 * z) = v;
-        return;
-    }
-#endif
-#pragma unroll
-    for (int z = 0; z < 4; ++z) *(uint4 *)(O + zs * z) = v;
+    for (int z = 0; z < 4; ++z) store_out16(O + zs * z, v);
 }
 
 __global__ void __launch_bounds__(64 * DEC_WAVES)
@@ -869,9 +867,6 @@ k_decode_fine(TileArgs a)
 #define QD_TPW 16           // tiles per wave: amortises the table copy
 #endif
 #define QD_TS 68            // tile row stride in words (as FD_TS)
-#ifndef QD_PAIRSTEPS
-#define QD_PAIRSTEPS 1      // two steps per loop trip (independent chains interleave)
-#endif
 #ifndef QD_PF
 #define QD_PF 4             // steps the stream-word requests run ahead
 #endif
@@ -1104,20 +1099,16 @@ k_decode_quad(TileArgs a)
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             // ---- 16 steps of 4 blocks x 16 lanes.  The stream words of a step are requested QD_PF steps ahead
-            uint32_t qw[QD_PF][4], qb[QD_PF], qV[QD_PF];
-            bool qLive[QD_PF];
+            // (a slot holds the four words only: scalar, bit offset and root flag are re-read from the park word when the
+            // step runs -- two LDS reads per step buy twice the request depth in the same registers)
+            uint32_t qw[QD_PF][4];
 #pragma unroll
-            for (int i = 0; i < QD_PF; ++i) { qw[i][0] = qw[i][1] = qw[i][2] = qw[i][3] = 0; qb[i] = 0; qV[i] = 0; qLive[i] = false; }
+            for (int i = 0; i < QD_PF; ++i) qw[i][0] = qw[i][1] = qw[i][2] = qw[i][3] = 0;
             const auto request = [&](int it, int slot) {
                 if ((((uint32_t)(liveMask >> (4 * it))) & 15u) == 0u) return;       // wave-uniform
                 const int S = 4 * it + (lane >> 4);
-                const uint32_t so = offS[wave][S];
-                const uint32_t tw = tile[g * QD_TS + S];
-                qV[slot] = tw & 255u;
-                const uint32_t tokpos = so + ((tw >> 8) & 1023u);
+                const uint32_t tokpos = offS[wave][S] + ((tile[g * QD_TS + S] >> 8) & 1023u);
                 const uint32_t *Wp = W + (tokpos >> 4);
-                qb[slot] = (tokpos & 15u) * 2u;
-                qLive[slot] = (tw & 0x40000u) != 0u;
                 qw[slot][0] = Wp[0]; qw[slot][1] = Wp[1]; qw[slot][2] = Wp[2]; qw[slot][3] = Wp[3];
             };
 #pragma unroll
@@ -1141,20 +1132,21 @@ k_decode_quad(TileArgs a)
                                              qd, chainS, used2);
                 return b01 | (b23 << 16);
             };
-#if QD_PAIRSTEPS
             // two steps per trip: their dependency chains (parse -> table lookups -> clamp-adds) are independent, so the
             // scheduler can fill one's LDS waits with the other's arithmetic (a CU holds only 4 such waves per SIMD)
 #pragma unroll
             for (int ip = 0; ip < 8; ++ip) {
                 const int i0 = 2 * ip, i1 = 2 * ip + 1, s0 = i0 % QD_PF, s1 = i1 % QD_PF;
                 const bool live0 = (((uint32_t)(liveMask >> (4 * i0))) & 15u) != 0u, live1 = (((uint32_t)(liveMask >> (4 * i1))) & 15u) != 0u;
-                const uint32_t a0 = qw[s0][0], a1 = qw[s0][1], a2 = qw[s0][2], a3 = qw[s0][3], ab = qb[s0];
-                const uint32_t c0 = qw[s1][0], c1 = qw[s1][1], c2 = qw[s1][2], c3 = qw[s1][3], cb = qb[s1];
-                const int aV = (int)qV[s0], cV = (int)qV[s1];
-                const bool aL = qLive[s0], cL = qLive[s1];
+                const int S0 = 4 * i0 + (lane >> 4), S1 = 4 * i1 + (lane >> 4);
+                const uint32_t a0 = qw[s0][0], a1 = qw[s0][1], a2 = qw[s0][2], a3 = qw[s0][3];
+                const uint32_t c0 = qw[s1][0], c1 = qw[s1][1], c2 = qw[s1][2], c3 = qw[s1][3];
+                const uint32_t twA = tile[g * QD_TS + S0], twC = tile[g * QD_TS + S1];
+                const uint32_t ab = ((offS[wave][S0] + (twA >> 8)) & 15u) * 2u, cb = ((offS[wave][S1] + (twC >> 8)) & 15u) * 2u;
+                const int aV = (int)(twA & 255u), cV = (int)(twC & 255u);
+                const bool aL = (twA & 0x40000u) != 0u, cL = (twC & 0x40000u) != 0u;
                 if (i0 + QD_PF < 16) request(i0 + QD_PF, s0);
                 if (i1 + QD_PF < 16) request(i1 + QD_PF, s1);
-                const int S0 = 4 * i0 + (lane >> 4), S1 = 4 * i1 + (lane >> 4);
                 if (live0 && live1) {
                     const uint32_t r0 = compute(a0, a1, a2, a3, ab, aV, aL), r1 = compute(c0, c1, c2, c3, cb, cV, cL);
                     tile[g * QD_TS + S0] = r0;
@@ -1162,18 +1154,6 @@ k_decode_quad(TileArgs a)
                 } else if (live0) tile[g * QD_TS + S0] = compute(a0, a1, a2, a3, ab, aV, aL);
                 else if (live1) tile[g * QD_TS + S1] = compute(c0, c1, c2, c3, cb, cV, cL);
             }
-#else
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const bool liveStep = (((uint32_t)(liveMask >> (4 * it))) & 15u) != 0u;   // wave-uniform
-                const int slot = it % QD_PF;
-                const uint32_t w0 = qw[slot][0], w1 = qw[slot][1], w2 = qw[slot][2], w3 = qw[slot][3], b = qb[slot];
-                const int V3 = (int)qV[slot];
-                const bool live = qLive[slot];
-                if (it + QD_PF < 16) request(it + QD_PF, slot);
-                if (liveStep) tile[g * QD_TS + 4 * it + (lane >> 4)] = compute(w0, w1, w2, w3, b, V3, live);
-            }
-#endif
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
