@@ -88,6 +88,64 @@ k_pyramid(Geom g, int dLeaf, int L, const uint8_t *__restrict__ vox, const uint8
     }
 }
 
+#ifndef ENC_NT
+#define ENC_NT 1
+#endif
+// level arrays are written by one whole-volume pass and read by the next: nothing of them survives in a cache until
+// then, so the large stores stream past it
+__device__ __forceinline__ void st16(void *p, uint4 v)
+{
+#if ENC_NT
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, (u32x4 *)p);
+#else
+    *(uint4 *)p = v;
+#endif
+}
+__device__ __forceinline__ void st8(void *p, uint2 v)
+{
+#if ENC_NT
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, (u32x2 *)p);
+#else
+    *(uint2 *)p = v;
+#endif
+}
+__device__ __forceinline__ void st4(void *p, uint32_t v)
+{
+#if ENC_NT
+    __builtin_nontemporal_store(v, (uint32_t *)p);
+#else
+    *(uint32_t *)p = v;
+#endif
+}
+
+#ifndef ENC_NTL
+#define ENC_NTL 1
+#endif
+__device__ __forceinline__ uint4 ld16(const void *p)
+{
+#if ENC_NTL
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = __builtin_nontemporal_load((const u32x4 *)p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return *(const uint4 *)p;
+#endif
+}
+__device__ __forceinline__ uint2 ld8(const void *p)
+{
+#if ENC_NTL
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 t = __builtin_nontemporal_load((const u32x2 *)p);
+    return make_uint2(t.x, t.y);
+#else
+    return *(const uint2 *)p;
+#endif
+}
+
 // Bottom 12 levels in one block: the 4096 leaves under one depth-(D-12) node form a
 // 2^ax x 2^ay x 2^az box (ax+ay+az = 12).  With ax >= 4 every thread fetches one aligned
 // 16-byte x-run of voxels (coalesced), scatters it to Morton order in LDS, and the block
@@ -150,7 +208,7 @@ k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__re
     __syncthreads();
     // 16 Morton-consecutive leaves per thread: they and the four levels above them never leave registers
     const uint4 lv = *(const uint4 *)(&leaf[t * 16]);
-    *(uint4 *)(T + ((int64_t)1 << D) + base + t * 16) = lv;                         // leaf: (v+v)/2 = v
+    st16(T + ((int64_t)1 << D) + base + t * 16, lv);                                // leaf: (v+v)/2 = v
     if (TR) *(uint4 *)(TR + ((int64_t)1 << D) + base + t * 16) = make_uint4(0, 0, 0, 0);
     const uint32_t w[4] = {lv.x, lv.y, lv.z, lv.w};
     vr_s16x2 mn1[4], mx1[4];
@@ -165,7 +223,7 @@ k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__re
     }
     {
         const int64_t o = ((int64_t)1 << (D - 1)) + (base >> 1) + t * 8;
-        *(uint2 *)(T + o) = make_uint2(__builtin_amdgcn_perm(md[1], md[0], 0x06040200u), __builtin_amdgcn_perm(md[3], md[2], 0x06040200u));
+        st8(T + o, make_uint2(__builtin_amdgcn_perm(md[1], md[0], 0x06040200u), __builtin_amdgcn_perm(md[3], md[2], 0x06040200u)));
         if (TR) *(uint2 *)(TR + o) = make_uint2(__builtin_amdgcn_perm(hr[1], hr[0], 0x06040200u), __builtin_amdgcn_perm(hr[3], hr[2], 0x06040200u));
     }
     vr_s16x2 mn2[2], mx2[2];
@@ -176,7 +234,7 @@ k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__re
     }
     {
         const int64_t o = ((int64_t)1 << (D - 2)) + (base >> 2) + t * 4;
-        *(uint32_t *)(T + o) = __builtin_amdgcn_perm(pk_mid(mn2[1], mx2[1]), pk_mid(mn2[0], mx2[0]), 0x06040200u);
+        st4(T + o, __builtin_amdgcn_perm(pk_mid(mn2[1], mx2[1]), pk_mid(mn2[0], mx2[0]), 0x06040200u));
         if (TR) *(uint32_t *)(TR + o) = __builtin_amdgcn_perm(pk_half_range(mn2[1], mx2[1]), pk_half_range(mn2[0], mx2[0]), 0x06040200u);
     }
     const vr_s16x2 mn3 = pk_pair_min(pk_u(mn2[0]), pk_u(mn2[1])), mx3 = pk_pair_max(pk_u(mx2[0]), pk_u(mx2[1]));   // level D-3
@@ -433,7 +491,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     uint4 tvN = make_uint4(0, 0, 0, 0);
     uint2 pvN = make_uint2(0, 0);
     bool skipN = seg0 < nseg && skip_block(sk, brick, d, seg0 * EST_SEG);       // a segment inside a skipped block: all zero, unread
-    if (seg0 < nseg && !skipN) { tvN = *(const uint4 *)(Tl + (size_t)seg0 * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)seg0 * (EST_SEG / 2)); }
+    if (seg0 < nseg && !skipN) { tvN = ld16(Tl + (size_t)seg0 * EST_SEG); pvN = ld8(Pl + (size_t)seg0 * (EST_SEG / 2)); }
     for (uint32_t seg = seg0; seg < nseg; seg += gridDim.x * 4) {
     const uint4 tv = tvN;
     const uint2 pv = pvN;
@@ -441,7 +499,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
     {
         const uint32_t sn = seg + gridDim.x * 4;
         skipN = sn < nseg && skip_block(sk, brick, d, sn * EST_SEG);
-        if (sn < nseg && !skipN) { tvN = *(const uint4 *)(Tl + (size_t)sn * EST_SEG); pvN = *(const uint2 *)(Pl + (size_t)sn * (EST_SEG / 2)); }
+        if (sn < nseg && !skipN) { tvN = ld16(Tl + (size_t)sn * EST_SEG); pvN = ld8(Pl + (size_t)sn * (EST_SEG / 2)); }
     }
     if (skipped) {
         uint32_t *outz = summ + (int64_t)brick * summStride * (4 * EST_CAND);
@@ -684,7 +742,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     const bool skipped = skip_block(sk, brick, d, (uint32_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) << 10);
     uint4 tv = make_uint4(0, 0, 0, 0);
     uint2 pv = make_uint2(0, 0);
-    if (!skipped) { tv = *(const uint4 *)(T + i0); pv = *(const uint2 *)(P + (i0 >> 1)); }
+    if (!skipped) { tv = ld16(T + i0); pv = ld8(P + (i0 >> 1)); }
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
     const uint32_t d2 = (uint32_t)dist * 0x10001u, dm2 = (uint32_t)distM * 0x10001u, dp2 = (uint32_t)distP * 0x10001u;
     uint32_t e0 = 0, em = 0, ep = 0, wa = 0, wb = 0, rw[4] = {tw[0], tw[1], tw[2], tw[3]}, rprev = 0;
@@ -719,8 +777,8 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     // even nodes sit at bits 4j, odd ones at 16+4j: fold to 2 bits per node
     const uint32_t cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
     if (!skipped) {
-        *(uint32_t *)(Cd + (i0 >> 2)) = cpk;
-        *(uint4 *)(R + i0) = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+        st4(Cd + (i0 >> 2), cpk);
+        st16(R + i0, make_uint4(rw[0], rw[1], rw[2], rw[3]));
     }
     // per-lane sums are < 2^21, a wave's < 2^27: 32-bit DPP scans, the total in lane 63
     unsigned long long s0 = 0, sm = 0, sp = 0;
