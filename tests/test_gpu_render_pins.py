@@ -318,3 +318,29 @@ def test_skip_grid_frames_are_bit_identical(vr, cell):
             skipped = vr.raycast(dvol, (X, Y, Z), cam, P).cpu().numpy()
             assert np.array_equal(plain, skipped), (pos, mode, iso)
             assert mode != 0 or pos[2] > 0 or (plain[..., 0] < 1).any()      # (a camera inside the cube starts at the exit face)
+
+
+@pytest.mark.parametrize("dims", [(128, 24, 17), (256, 40, 24), (384, 9, 8)])
+def test_skip_grid_strip_kernel_equals_definition(vr, monkeypatch, dims):
+    """k_skip_grid8 (rows that are multiples of 128 voxels, 8-voxel cells: one wave per strip of 16 cells) against
+    the definition -- (min, max) over [8c, 8c + 8] per axis, clamped to the volume -- for every cell, and against the
+    one-wave-per-cell kernel."""
+    import torch
+    X, Y, Z = dims
+    rng = np.random.default_rng(X + Y)
+    vol = rng.integers(0, 256, (Z, Y, X), dtype=np.uint8)
+    vol[:, :, 100:140] = 7                    # a constant band across a strip boundary
+    vol[2:6, 3:9, :] = rng.integers(100, 110, (4, 6, X))
+    dvol = torch.from_numpy(vol).cuda().reshape(-1)
+    g = vr.build_skip_grid(dvol, (X, Y, Z), 8).cpu().numpy().reshape(-1, 2)
+    n = [(q + 7) // 8 for q in (X, Y, Z)]
+    want = np.empty((n[2], n[1], n[0], 2), np.uint8)
+    for cz in range(n[2]):
+        for cy in range(n[1]):
+            for cx in range(n[0]):
+                blk = vol[cz * 8:cz * 8 + 9, cy * 8:cy * 8 + 9, cx * 8:cx * 8 + 9]
+                want[cz, cy, cx] = (blk.min(), blk.max())
+    assert np.array_equal(g, want.reshape(-1, 2))
+    monkeypatch.setenv("VRHIP_SKIP_GRID_V1", "1")
+    g1 = vr.build_skip_grid(dvol, (X, Y, Z), 8).cpu().numpy().reshape(-1, 2)
+    assert np.array_equal(g1, g)
