@@ -168,7 +168,7 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.blockVal, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockSpine, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     if (b.variant == VR_VARIANT_MIDRANGE) HIPCHK(hipMalloc(&b.blockSpineR, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&b.chainLut, 260 * sizeof(uint32_t)));   // 256 entries + [256]: entries that would need the zero-run rewrite
+    HIPCHK(hipMalloc(&b.chainLut, (260 + 512) * sizeof(uint32_t)));   // 256 entries + [256]: entries that would need the zero-run rewrite; + 512 keyed by the signed error
     HIPCHK(hipMalloc(&b.blockTot, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     if (b.idx64) {

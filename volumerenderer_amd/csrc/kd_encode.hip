@@ -1139,6 +1139,7 @@ k_prune_level(int d, const Ctrl *ctrls, uint8_t *__restrict__ codes, uint8_t *__
 // first; byte-aligned so that two entries fold into packed lanes with one v_perm each); the other side swaps
 // add <-> sub.  Leaves with m0 > min(t, 255 - t) take
 // the exact step-by-step path.
+#define VR_CHAIN_LUT_SIGNED 260     // word offset of the signed-key table inside BrickSet::chainLut (512 entries)
 __global__ void k_chain_lut(int tol, int nsteps, uint32_t *__restrict__ lut)
 {
     const int m0 = threadIdx.x, t = 128;
@@ -1152,6 +1153,11 @@ __global__ void k_chain_lut(int tol, int nsteps, uint32_t *__restrict__ lut)
     }
     const int fe = rec > t ? rec - t : t - rec;
     lut[m0] = (uint32_t)fe | (n << 8) | (bits << 16);     // byte 0: final error, byte 1: token count, bytes 2-3: tokens
+    // the same keyed by the SIGNED error truth - reconstruction (9 bits, at lut + VR_CHAIN_LUT_SIGNED): a negative error
+    // takes the mirrored branch (add <-> sub), so k_prune_emit12 needs neither the mirror nor the select
+    lut[VR_CHAIN_LUT_SIGNED + m0] = lut[m0];
+    if (m0 >= 1) lut[VR_CHAIN_LUT_SIGNED + 512 - m0] = (uint32_t)fe | (n << 8) | ((bits ^ (((bits ^ (bits >> 1)) & 0x1555u) * 3u)) << 16);
+    if (m0 == 0) lut[VR_CHAIN_LUT_SIGNED + 256] = 0;
     // entries 0..127 are the ones a leaf can reach through the table (m0 <= min(t, 255 - t)); one that ends on a
     // "keep" would need the reference's zero-run rewrite (R.cpp:662-669,686-688): counted, asserted zero by the tests
     const int zr = __syncthreads_count(m0 <= 127 && lastKeep);
@@ -1527,7 +1533,7 @@ template <bool RANGE>
 __global__ void __launch_bounds__(256, RANGE ? 4 : 6)
 k_prune_emit12(PruneEmitArgs a)
 {
-    __shared__ uint32_t lutS[256];
+    __shared__ uint32_t lutS[512];                   // grown branch by signed initial error (k_chain_lut)
     __shared__ uint32_t W[PE_WORDS];
     __shared__ uint8_t codeH[256], codeOldH[256];    // the block's nodes of depths D-12 .. D-5, heap order (1 .. 255)
     __shared__ uint8_t flH[512];                     // "subtree is a single pruned token" flags; 256 + t = the depth-(D-4) nodes
@@ -1540,7 +1546,7 @@ k_prune_emit12(PruneEmitArgs a)
     const uint32_t blk = blockIdx.x, base = blk << 12;
     uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
     // ---- every global load of the block, in one batch
-    const uint32_t lutV = a.chainLut[t];
+    const uint32_t lutV = a.chainLut[VR_CHAIN_LUT_SIGNED + t], lutV2 = a.chainLut[VR_CHAIN_LUT_SIGNED + 256 + t];
     const int hU = t ? t : 1, lqU = 31 - __clz(hU);
     const int64_t niU = ((int64_t)1 << (D - 12 + lqU)) + ((int64_t)blk << lqU) + (hU - (1 << lqU));
     const uint32_t upB = Cb[niU >> 2];
@@ -1572,7 +1578,7 @@ k_prune_emit12(PruneEmitArgs a)
         tvR = *(const uint4 *)(a.tempR + (int64_t)brick * a.heapStride + li);
         rvR = *(const uint4 *)((cParR == 0 ? a.rbR.b[0] : (cParR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
     }
-    lutS[t] = lutV;
+    lutS[t] = lutV; lutS[256 + t] = lutV2;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
     for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
     // ---- a block of 4096 exactly reproduced leaves under all-"keep" codes (constant regions) is one pruned subtree:
@@ -1611,7 +1617,7 @@ k_prune_emit12(PruneEmitArgs a)
     // one '3' per leaf, no branches, no statistics to add
     const bool busy = __ballot(!plain) != 0ull;
     if (!busy) {
-        bothMask = 0xFFu;
+        bothMask = 0x5555u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { nt[j] = 0x00010001u; Lb[j] = 0x00030003u; }
     }
@@ -1636,14 +1642,13 @@ k_prune_emit12(PruneEmitArgs a)
             const uint32_t newp = isz & lt;
             const uint32_t pruned = newp | is3;
             const uint32_t lcode = cl2 | (newp & 0x00030003u);
-            bothMask |= ((pruned & (pruned >> 16)) & 1u) << j;
+            bothMask |= ((pruned & (pruned >> 16)) & 1u) << (2 * j);     // at the bit of the pair node's code (below)
             const vr_s16x2 lim = __builtin_elementwise_min(pk_s(T2[jj]), pk_s(T2[jj] ^ 0x00FF00FFu));
             const uint32_t viol = pk_u((lim - mm) >> 15);                                          // a clamp could matter
-            const uint32_t e0 = lutS[m[jj] & 255u], e1 = lutS[(m[jj] >> 16) & 255u];
+            const uint32_t e0 = lutS[pk_u(dl) & 511u], e1 = lutS[(pk_u(dl) >> 16) & 511u];         // keyed by the signed error
             const uint32_t useL = ~pruned & ~viol;
             const uint32_t ch2 = __builtin_amdgcn_perm(e1, e0, 0x07060302u);                           // the two token strings
-            const uint32_t mir = ch2 ^ (((ch2 ^ (ch2 >> 1)) & 0x15551555u) * 3u);                   // add <-> sub
-            Lb[j] = lcode | ((useL & ((sg[jj] & mir) | (~sg[jj] & ch2))) << 2);
+            Lb[j] = lcode | ((useL & ch2) << 2);
             nt[j] = 0x00010001u + (useL & __builtin_amdgcn_perm(e1, e0, 0x0c050c01u));            // the two counts
             m[jj] = (useL & __builtin_amdgcn_perm(e1, e0, 0x0c040c00u)) | (~useL & m[jj]);         // the two final errors
             act[jj] = ~pruned & viol;
@@ -1719,46 +1724,36 @@ k_prune_emit12(PruneEmitArgs a)
             LbR[j] = both;
         }
     }
-    // ---- depths D-1 .. D-4 of my 16 leaves, in registers (R.cpp:596-629: a node only depends on its children)
-    uint32_t a1 = c1H, a2 = c2B, f1 = 0, f2 = 0, f3m = 0;      // new codes (2 bits each), pruned-token flags
+    // ---- depths D-1 .. D-4 of my 16 leaves, in registers (R.cpp:596-629: a node only depends on its children), all
+    // nodes of a level at once: the eight depth-(D-1) codes sit at bits 2k, the four depth-(D-2) codes at bits 4q, the
+    // two depth-(D-3) codes at bits 8r, the depth-(D-4) code at bit 0 -- a node's children are the codes at its own bit
+    // position and at the next position of the finer level, so "both children are pruned tokens" is one AND of shifts
+    uint32_t a1 = c1H;
+    uint32_t a2 = c2B; a2 = (a2 | (a2 << 4)) & 0x0F0Fu; a2 = (a2 | (a2 << 2)) & 0x3333u;
+    uint32_t a3 = (c3B >> ((int)(n3 & 3) * 2)) & 15u; a3 = (a3 | (a3 << 6)) & 0x0303u;
+    uint32_t a4 = (c4B >> ((int)(n4 & 3) * 2)) & 3u;
+    const auto prune_level = [](uint32_t &codes, uint32_t bothChildren, uint32_t at) -> uint32_t {
+        const uint32_t keep = ~(codes | (codes >> 1)) & at;          // code == 0
+        const uint32_t p = keep & bothChildren;                       // ... and both children pruned: becomes a 3
+        codes |= p | (p << 1);
+        return codes & (codes >> 1) & at;                             // the level's pruned tokens
+    };
+    const uint32_t F1 = prune_level(a1, bothMask, 0x5555u);
+    const uint32_t F2 = prune_level(a2, F1 & (F1 >> 2), 0x1111u);
+    const uint32_t F3 = prune_level(a3, F2 & (F2 >> 4), 0x0101u);
+    const uint32_t F4 = prune_level(a4, F3 & (F3 >> 8), 0x0001u);
+    // tokens a subtree emits: 1 if its root is a pruned token, else 1 + its children's
     int cnt1[8], cnt2[4], cnt3[2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t code = (a1 >> (2 * k)) & 3u;
-        const bool p = ((bothMask >> k) & 1u) && code == 0;
-        if (p) a1 |= 3u << (2 * k);
-        const bool f = p || code == 3;
-        f1 |= (f ? 1u : 0u) << k;
-        cnt1[k] = f ? 1 : 1 + (int)(nt[k] & 0xFFFFu) + (int)(nt[k] >> 16);
-    }
+    for (int k = 0; k < 8; ++k)
+        cnt1[k] = 1 + (((int)(nt[k] & 0xFFFFu) + (int)(nt[k] >> 16)) & ~__builtin_amdgcn_sbfe((int)F1, 2 * k, 1));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t code = (a2 >> (2 * q)) & 3u;
-        const bool p = ((f1 >> (2 * q)) & 3u) == 3u && code == 0;
-        if (p) a2 |= 3u << (2 * q);
-        const bool f = p || code == 3;
-        f2 |= (f ? 1u : 0u) << q;
-        cnt2[q] = f ? 1 : 1 + cnt1[2 * q] + cnt1[2 * q + 1];
-    }
-    uint32_t a3 = (c3B >> ((int)(n3 & 3) * 2)) & 15u;           // my two depth-(D-3) codes
+    for (int q = 0; q < 4; ++q) cnt2[q] = 1 + ((cnt1[2 * q] + cnt1[2 * q + 1]) & ~__builtin_amdgcn_sbfe((int)F2, 4 * q, 1));
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint32_t code = (a3 >> (2 * r)) & 3u;
-        const bool p = ((f2 >> (2 * r)) & 3u) == 3u && code == 0;
-        if (p) a3 |= 3u << (2 * r);
-        const bool f = p || code == 3;
-        f3m |= (f ? 1u : 0u) << r;
-        cnt3[r] = f ? 1 : 1 + cnt2[2 * r] + cnt2[2 * r + 1];
-    }
-    uint32_t a4 = (c4B >> ((int)(n4 & 3) * 2)) & 3u;            // my depth-(D-4) code
-    {
-        const bool p = f3m == 3u && a4 == 0;
-        if (p) a4 = 3u;
-        const bool f = a4 == 3u;
-        flH[256 + t] = (uint8_t)(f ? 1 : 0);
-        cntH[256 + t] = (uint16_t)(f ? 1 : 1 + cnt3[0] + cnt3[1]);
-    }
-    const int cnt4 = a4 == 3u ? 1 : 1 + cnt3[0] + cnt3[1];
+    for (int r = 0; r < 2; ++r) cnt3[r] = 1 + ((cnt2[2 * r] + cnt2[2 * r + 1]) & ~__builtin_amdgcn_sbfe((int)F3, 8 * r, 1));
+    const int cnt4 = 1 + ((cnt3[0] + cnt3[1]) & ~__builtin_amdgcn_sbfe((int)F4, 0, 1));
+    flH[256 + t] = (uint8_t)F4;
+    cntH[256 + t] = (uint16_t)cnt4;
     __syncthreads();
     // ---- depths D-5 .. D-12 in LDS
     for (int lq = 7; lq >= 0; --lq) {
@@ -1777,9 +1772,11 @@ k_prune_emit12(PruneEmitArgs a)
     // (M.cpp:864-865); the shape (which tokens exist) is unchanged because a token is 3 in both streams or in neither
     if (RANGE) {
         const auto merge = [](uint32_t mid, uint32_t rng) { const uint32_t m3 = (mid & (mid >> 1) & 0x55555555u) * 3u; return (rng & ~m3) | m3; };
+        uint32_t r2 = c2BR; r2 = (r2 | (r2 << 4)) & 0x0F0Fu; r2 = (r2 | (r2 << 2)) & 0x3333u;      // spread like a2, a3
+        uint32_t r3 = (c3BR >> ((int)(n3 & 3) * 2)) & 15u; r3 = (r3 | (r3 << 6)) & 0x0303u;
         a1 = merge(a1, c1HR) & 0xFFFFu;
-        a2 = merge(a2, c2BR) & 0xFFu;
-        a3 = merge(a3, (c3BR >> ((int)(n3 & 3) * 2)) & 15u) & 15u;
+        a2 = merge(a2, r2) & 0x3333u;
+        a3 = merge(a3, r3) & 0x0303u;
         a4 = merge(a4, (c4BR >> ((int)(n4 & 3) * 2)) & 3u) & 3u;
         const uint8_t ro = (uint8_t)((upBR >> ((int)(niU & 3) * 2)) & 3u);
         const uint8_t mc = codeH[t];
@@ -1830,13 +1827,13 @@ k_prune_emit12(PruneEmitArgs a)
         if (a4 != 3u) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const uint32_t c3 = (a3 >> (2 * r)) & 3u;
+                const uint32_t c3 = (a3 >> (8 * r)) & 3u;
                 pb |= (unsigned long long)c3 << (2 * pn); ++pn;
                 if (c3 == 3u) continue;
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * r + qq;
-                    const uint32_t c2 = (a2 >> (2 * q)) & 3u;
+                    const uint32_t c2 = (a2 >> (4 * q)) & 3u;
                     pb |= (unsigned long long)c2 << (2 * pn); ++pn;
                     if (c2 == 3u) continue;
 #pragma unroll
@@ -1867,7 +1864,7 @@ k_prune_emit12(PruneEmitArgs a)
         // decoder turns them into token offsets with a 16-lane prefix sum, so one lane decodes four voxels.
         const int nsIn = jmin <= 6 ? (aliveAtDs ? ns - preDs : 0) : ns;
         const bool l4 = alive && a4 != 3u;
-        const bool l30 = l4 && (a3 & 3u) != 3u, l31 = l4 && ((a3 >> 2) & 3u) != 3u;
+        const bool l30 = l4 && (a3 & 3u) != 3u, l31 = l4 && ((a3 >> 8) & 3u) != 3u;
         const uint32_t f0 = (uint32_t)(nsIn + (alive ? 1 + (l4 ? 1 + (l30 ? cnt2[0] : 0) : 0) : 0));
         const uint32_t f1 = (uint32_t)(l30 ? cnt2[1] : 0);
         const uint32_t f2 = (uint32_t)(l4 ? 1 + (l31 ? cnt2[2] : 0) : 0);
