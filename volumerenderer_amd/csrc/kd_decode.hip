@@ -846,7 +846,7 @@ k_decode_fine(TileArgs a)
 // Same tile, same side-car counts as k_decode_fine, one lane per four voxels, but nothing on the step's critical
 // path waits for LDS and a voxel leaf is ONE table lookup:
 //   * the scalars of the depth-(D-3) nodes come from a third side-car (8 bytes per depth-Ds node, written by
-//     k_concat12 / the host parse), so the per-tile pass that decoded the 15 upper nodes of every block -- and
+//     k_index12 / the host parse), so the per-tile pass that decoded the 15 upper nodes of every block -- and
 //     re-read their tokens -- is gone: a tile starts by parking (scalar, count) per 4-leaf subtree;
 //   * a lane's tokens (at most 4 + 3 + 4 * 8 = 39) sit in three 32-bit windows cut from its four stream words with
 //     v_alignbit; where a leaf ends follows from the positions of the '3' tokens in its window
@@ -856,7 +856,9 @@ k_decode_fine(TileArgs a)
 //     brick (R.cpp:94-97), so ONE table serves the launch (64 KiB of LDS per 16-wave workgroup); tokens behind the
 //     first '3' are forced to '3' before the lookup, so a leaf's key never depends on its successor's tokens;
 //   * a pruned node is a token that reads as '3' (also forced where an ancestor is pruned): its subtree's voxels take
-//     its parent's scalar through selects, never through exec-mask branches.
+//     its parent's scalar through selects, never through exec-mask branches;
+//   * the workgroup's front end (index pre-pass into LDS, two tickets per wave, ticket order by emit block, per-level
+//     delta tables) and what bounds the launch are described at the kernel and in DESIGN.md 3.3.
 #ifndef QD_WAVES
 #define QD_WAVES 16
 #endif
