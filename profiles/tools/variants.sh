@@ -1,0 +1,7 @@
+#!/bin/bash
+# usage: [DEC_SCRIPT=profiles/tools/dec_split.py] profiles/tools/variants.sh "flagsA" "flagsB" ...   (each variant rebuilds libvrhip.so and times the decode)
+cd /root/repo
+for f in "$@"; do
+  echo "=== variant: $f"
+  VRHIP_EXTRA_HIPCC_FLAGS="$f" TAG="$f" timeout -k 10 400 python ${DEC_SCRIPT:-profiles/tools/dec_time.py} 2>&1 | grep -v amdgpu.ids
+done
