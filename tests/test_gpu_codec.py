@@ -660,3 +660,21 @@ def test_constant_blocks_skipped_by_the_level_loop(vr, oracle, monkeypatch, tol,
     assert np.array_equal(plain.tree(0), bs.tree(0))
     assert list(plain.distance_map(0)) == list(bs.distance_map(0))
     assert plain.info(0) == bs.info(0)
+
+
+def test_midrange_range_decode_below_pruned_blocks(vr, oracle):
+    """Regression (found by scratch fuzzing, 2 of 250 cases): a 4096-leaf block that the mid stream prunes as a whole
+    keeps, in the half-range stream's code ARRAY, whatever the range level loop chose below its root; the range
+    stream itself ends there (M.cpp:864-865).  The scalars decode_range starts from must stop at the pruned node."""
+    cases = np.load(os.path.join(os.path.dirname(__file__), "golden", "midrange_range_decode_cases.npz"))
+    for name, tol, ep in (("case53_tol5_ep2", 5, 2), ("case149_tol2_ep1", 2, 1)):
+        vol = cases[name]
+        z, y, x = vol.shape
+        ref = oracle.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep, midrange=True, guarded=True).build()
+        bs = vr.BrickSet(1, (x, y, z), tol, ep, 2)
+        bs.build(vol.copy())
+        assert np.array_equal(bs.tree(0), ref.tree) and np.array_equal(bs.tree_range(0), ref.tree_range)
+        D = ref.origTreeDepth
+        for cut in (None, D, D - 3, D - 6, D - 7, D - 12, 4):
+            got = bs.decode_range(cut_depth=-1 if cut is None else cut).cpu().numpy().reshape(vol.shape)
+            assert np.array_equal(got, ref.levelCutRange(cut)), (name, cut)

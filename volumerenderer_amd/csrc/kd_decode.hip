@@ -1211,7 +1211,14 @@ k_cut_values(const uint8_t *__restrict__ codes, int64_t codeStride, const Ctrl *
     const uint8_t *Cb = codes + (int64_t)brick * codeStride;
     const uint8_t *dmap = ctrls[brick].distanceMap;
     int val = dmap[0];
-    for (int j = 1; j <= cut; ++j) val = apply_code(val, cget(Cb, ((int64_t)1 << j) + (s >> (Ds - j))), dmap[j]);
+    // a pruned node ends the path: what the level loop left in the array below it is not part of the tree.  (In the mid
+    // stream those codes are all "keep" or 3 anyway; in a MidRangeTree's half-range stream, pruned where the mid stream
+    // is, M.cpp:864-865, they are whatever its own level loop chose.)
+    for (int j = 1; j <= cut; ++j) {
+        const int code = cget(Cb, ((int64_t)1 << j) + (s >> (Ds - j)));
+        if (code == 3) break;
+        val = apply_code(val, code, dmap[j]);
+    }
     out[(int64_t)brick * nIdx + s] = (uint8_t)val;
 }
 
