@@ -68,7 +68,7 @@ typedef struct vr_tree_info {
     int64_t num_active_nodes;    /* numActiveNodes (R.cpp:714)                     */
     int64_t tree_bytes;          /* tree.bytes() = ceil(numActiveNodes / 4)        */
     int32_t tolerance, max_epochs, variant;
-    int32_t num_reverts;         /* gradient-descent reverts taken (defect C-2 indicator) */
+    int32_t num_reverts;         /* gradient-descent reverts taken (defect C-2 indicator); MidRangeTree: both streams' */
     int32_t max_error_before;    /* encoder's own leaf max error before branch growth (R.cpp:71-76) */
     int32_t max_error_after;     /* ... after branch growth (R.cpp:115-120)        */
     double  mean_l1_after;       /* (R.cpp:122-129)                                */

@@ -603,7 +603,7 @@ def test_midrange_on_the_fused_kernels(vr, oracle, shape, tol, ep):
         ref = oracle.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep, midrange=True, guarded=True).build()
         bs = vr.BrickSet(1, (x, y, z), tol, ep, 2)
         bs.build(vol.copy())
-        assert bs.info(0)["num_active_nodes"] == ref.numActiveNodes
+        assert bs.info(0)["num_active_nodes"] == ref.numActiveNodes and bs.info(0)["num_reverts"] == ref.numReverts
         assert list(bs.distance_map(0)) == list(ref.distanceMap) and list(bs.distance_map_range(0)) == list(ref.distanceMap_range)
         assert np.array_equal(bs.tree(0), ref.tree)
         assert np.array_equal(bs.tree_range(0), ref.tree_range)

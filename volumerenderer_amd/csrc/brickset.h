@@ -70,6 +70,7 @@ struct BrickSet {
     uint8_t *rankVals = nullptr;   // B * 2^D * 2: decoded value | branch nodes << 8 of every leaf rank (general-extent decode scratch)
 
     std::vector<Ctrl> hostCtrl; // copied back lazily
+    std::vector<int32_t> hostRevertsR;   // MidRangeTree: reverted epochs of the half-range stream, per brick (sync_ctrl)
     uint32_t lutZeroRun = 0;    // chainLut[256]: table entries that would need the zero-run rewrite (always 0)
     bool encoderReady = false;  // every buffer of ensure_encoder_buffers (capi.hip) is allocated
     bool built = false, hostCtrlValid = false;

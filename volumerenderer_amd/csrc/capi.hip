@@ -327,6 +327,13 @@ static vr_status sync_ctrl(BrickSet &b)
     HIPCHK(hipMemcpy(b.hostCtrl.data(), b.mid.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
     b.lutZeroRun = 0;
     if (b.chainLut && !b.foreign) HIPCHK(hipMemcpy(&b.lutZeroRun, b.chainLut + 256, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // MidRangeTree: the half-range stream's level loop reverts epochs of its own (M.cpp:399-544)
+    b.hostRevertsR.assign((size_t)b.B, 0);
+    if (b.variant == VR_VARIANT_MIDRANGE && !b.foreign && b.rng.ctrl) {
+        std::vector<Ctrl> r((size_t)b.B);
+        HIPCHK(hipMemcpy(r.data(), b.rng.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
+        for (int i = 0; i < b.B; ++i) b.hostRevertsR[(size_t)i] = r[(size_t)i].constBrick ? 0 : r[(size_t)i].numReverts;
+    }
     b.hostCtrlValid = true;
     return VR_OK;
 }
@@ -346,7 +353,7 @@ vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
     info->num_active_nodes = (int64_t)c.numActive;
     info->tree_bytes = ((int64_t)c.numActive + 3) / 4;
     info->tolerance = b.tolerance; info->max_epochs = b.maxEpochs; info->variant = b.variant;
-    info->num_reverts = c.numReverts;
+    info->num_reverts = c.numReverts + ((size_t)brick < b.hostRevertsR.size() ? b.hostRevertsR[(size_t)brick] : 0);
     info->max_error_before = c.maxErrBefore;
     info->max_error_after = c.maxErrAfter;
     info->mean_l1_after = (double)c.statL1 / (double)b.leafStride;
