@@ -247,6 +247,10 @@ k_raycast(RayArgs a)
     } else {
         float col[4] = {1.0f, 1.0f, 1.0f, 1.0f};         // vec4(255,255,255,1) clamped (isosurface.frag:79)
         const float iso = a.P.iso_value;
+        // A step's second fetch is at dataPos + dirStep, which IS the next step's dataPos (the same float addition of
+        // the same operands): the shader fetches it twice (isosurface.frag:120-121), here the value is carried over.
+        float carried = 0.0f;
+        bool haveCarried = false;
         for (int i = 0; i < ns; ++i) {
             pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
             if (!inside(pos[0], pos[1], pos[2])) break;
@@ -254,12 +258,13 @@ k_raycast(RayArgs a)
                 // the test below needs s1 < iso <= s2.  Interpolation in float can leave the taps' range by rounding only,
                 // so a whole grey level of margin decides safely: every tap of s1 above iso, or every tap of s2 below it
                 const uint32_t b1 = skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]);
-                if ((float)((int)(b1 & 255u) - 1) * (1.0f / 255.0f) >= iso) continue;
+                if ((float)((int)(b1 & 255u) - 1) * (1.0f / 255.0f) >= iso) { haveCarried = false; continue; }
                 const uint32_t b2 = skip_bounds(a.sg, a.t, pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]);
-                if ((float)((int)(b2 >> 8) + 1) * (1.0f / 255.0f) < iso) continue;
+                if ((float)((int)(b2 >> 8) + 1) * (1.0f / 255.0f) < iso) { haveCarried = false; continue; }
             }
-            float s1 = tex3d(a.t, pos[0], pos[1], pos[2]);
+            float s1 = haveCarried ? carried : tex3d(a.t, pos[0], pos[1], pos[2]);
             float s2 = tex3d(a.t, pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]);
+            carried = s2; haveCarried = true;
             if ((s1 - iso) < 0.0f && (s2 - iso) >= 0.0f) {                     // :126
                 float l[3] = {pos[0], pos[1], pos[2]}, r[3] = {pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]};
                 for (int b = 0; b < 4; ++b) {                                  // Bisection :23-42
