@@ -218,12 +218,14 @@ k_raycast(RayArgs a)
     const int ns = a.P.max_samples;
     if (mode == VR_RENDER_COMPOSITE) {
         float rgb = 0.0f, A = 0.0f;
+        bool probe = true;      // ask the grid only while the ray is in empty space (the last fetch, if any, was 0)
         for (int i = 0; i < ns; ++i) {
             pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
             if (!inside(pos[0], pos[1], pos[2])) break;
             // all eight taps zero: the sample is exactly 0 and the three updates below are exact no-ops
-            if (a.sg.g && (skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]) >> 8) == 0u) continue;
+            if (a.sg.g && probe && (skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]) >> 8) == 0u) continue;
             float smp = tex3d(a.t, pos[0], pos[1], pos[2]);
+            probe = smp == 0.0f;
             float pa = smp - (smp * A);          // raycaster.frag:69
             rgb = pa * smp + rgb;                // :70
             A += pa * 0.6f;                      // :72
@@ -250,16 +252,20 @@ k_raycast(RayArgs a)
         // A step's second fetch is at dataPos + dirStep, which IS the next step's dataPos (the same float addition of
         // the same operands): the shader fetches it twice (isosurface.frag:120-121), here the value is carried over.
         float carried = 0.0f;
-        bool haveCarried = false;
+        bool haveCarried = false, haveBounds = false;
+        uint32_t carriedBounds = 0;
         for (int i = 0; i < ns; ++i) {
             pos[0] = pos[0] + st[0]; pos[1] = pos[1] + st[1]; pos[2] = pos[2] + st[2];
             if (!inside(pos[0], pos[1], pos[2])) break;
             if (a.sg.g) {
                 // the test below needs s1 < iso <= s2.  Interpolation in float can leave the taps' range by rounding only,
                 // so a whole grey level of margin decides safely: every tap of s1 above iso, or every tap of s2 below it
-                const uint32_t b1 = skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]);
+                // (the second position's bounds are the next step's first, like the fetch itself)
+                const uint32_t b1 = haveBounds ? carriedBounds : skip_bounds(a.sg, a.t, pos[0], pos[1], pos[2]);
+                haveBounds = false;
                 if ((float)((int)(b1 & 255u) - 1) * (1.0f / 255.0f) >= iso) { haveCarried = false; continue; }
                 const uint32_t b2 = skip_bounds(a.sg, a.t, pos[0] + st[0], pos[1] + st[1], pos[2] + st[2]);
+                carriedBounds = b2; haveBounds = true;
                 if ((float)((int)(b2 >> 8) + 1) * (1.0f / 255.0f) < iso) { haveCarried = false; continue; }
             }
             float s1 = haveCarried ? carried : tex3d(a.t, pos[0], pos[1], pos[2]);
