@@ -1698,30 +1698,43 @@ k_prune_emit12(PruneEmitArgs a)
     // terminator if it has one
     uint32_t LbR[8];
     if (RANGE) {
+        // sibling leaves in packed 16-bit lanes, like the mid stream's: per branch level one reduced encodeNode
+        // (kd_common.h) for both, applied where the mid stream's branch still has an evaluated node at that level;
+        // a wave leaves the level loop as soon as none of its branches is that long
         const uint32_t twR[4] = {tvR.x, tvR.y, tvR.z, tvR.w}, rwR[4] = {rvR.x, rvR.y, rvR.z, rvR.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            uint32_t both = 0;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int leaf = 2 * j + e;
-                const uint32_t midStr = (Lb[j] >> (16 * e)) & 0xFFFFu;
-                const int n = (int)((nt[j] >> (16 * e)) & 0xFFFFu) - 1;          // branch tokens of the mid stream
-                const bool prunedLeaf = (midStr & 3u) == 3u;
-                const bool hasTerm = n > 0 && ((midStr >> (2 * n)) & 3u) == 3u;
-                const int k = n - (hasTerm ? 1 : 0);                               // evaluated branch nodes
-                uint32_t bits = prunedLeaf ? 3u : ((cpkR >> (2 * leaf)) & 3u);
-                const int tR = (int)((twR[leaf >> 2] >> (8 * (leaf & 3))) & 255u);
-                int recR = (int)((rwR[leaf >> 2] >> (8 * (leaf & 3))) & 255u);
-#pragma unroll
-                for (int i = 0; i < VR_CHAIN_LEVELS; ++i) {
-                    const Enc en = encode_node(tR, recR, 64 >> i);
-                    if (i < k) { recR = en.recon; bits |= (uint32_t)en.code << (2 * i + 2); }
-                }
-                if (hasTerm) bits |= 3u << (2 * k + 2);
-                both |= bits << (16 * e);
+            if (!busy) { LbR[j] = 0x00030003u; continue; }
+            const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
+            const vr_s16x2 T2 = pk_s(__builtin_amdgcn_perm(0, twR[j >> 1], sel));
+            vr_s16x2 rec = pk_s(__builtin_amdgcn_perm(0, rwR[j >> 1], sel));
+            const uint32_t mid = Lb[j];
+            const vr_s16x2 n2 = pk_s(nt[j]) - pk_s(0x00010001u);                        // branch tokens of the mid stream
+            const uint32_t prunedM = ((mid & (mid >> 1)) & 0x00010001u) * 0xFFFFu;          // the leaf's own token is a 3
+            vr_u16x2 lastTok = __builtin_bit_cast(vr_u16x2, mid) >> __builtin_bit_cast(vr_u16x2, n2 + n2);   // token n of each string
+            const uint32_t lt = __builtin_bit_cast(uint32_t, lastTok);
+            const uint32_t hasN = pk_u((vr_s16x2)(0) - n2) >> 15 & 0x00010001u;            // n > 0
+            const uint32_t termB = (lt & (lt >> 1)) & hasN;                                 // bit 0 of each lane: has a terminator
+            const vr_s16x2 k2 = n2 - pk_s(termB);                                           // evaluated branch nodes
+            const uint32_t cR = ((cpkR >> (4 * j)) & 3u) | (((cpkR >> (4 * j + 2)) & 3u) << 16);
+            uint32_t bits = (prunedM & 0x00030003u) | (~prunedM & cR);
+            for (int i = 0; i < VR_CHAIN_LEVELS; ++i) {
+                const uint32_t am = pk_u((pk_s((uint32_t)i * 0x10001u) - k2) >> 15);       // 0xFFFF where k > i
+                if (__ballot(am != 0u) == 0ull) break;
+                const uint32_t d2 = (uint32_t)(64 >> i) * 0x10001u;
+                const vr_s16x2 diff = T2 - rec, nd = (vr_s16x2)(0) - diff;
+                const vr_s16x2 pd = __builtin_elementwise_max(diff, nd);
+                const uint32_t up = pk_u(nd >> 15);
+                const vr_s16x2 h = pk_s(pk_u(T2) ^ (up & 0x00FF00FFu));
+                const vr_s16x2 x = __builtin_elementwise_min(pk_s(d2) - pd, h), ax = pk_abs(x);
+                const uint32_t take = pk_u((ax - pd) >> 15) & am;
+                const uint32_t code2 = take & pk_u(pk_s(up) + pk_s(0x00020002u)) & 0x00030003u;    // up ? 1 : 2
+                const vr_s16x2 r = pk_mad(x, pk_mad(pk_s(up), pk_s(0xFFFEFFFEu), pk_s(0xFFFFFFFFu)), T2);   // up ? t + x : t - x
+                rec = pk_s((take & pk_u(r)) | (~take & pk_u(rec)));
+                bits |= code2 << (2 * i + 2);
             }
-            LbR[j] = both;
+            const vr_u16x2 term = __builtin_bit_cast(vr_u16x2, termB * 3u) << __builtin_bit_cast(vr_u16x2, k2 + k2 + pk_s(0x00020002u));
+            LbR[j] = bits | __builtin_bit_cast(uint32_t, term);
         }
     }
     // ---- depths D-1 .. D-4 of my 16 leaves, in registers (R.cpp:596-629: a node only depends on its children), all
