@@ -115,6 +115,33 @@ def test_constant_brick_closed_form(vr, oracle, shape):
         assert bs.info(i)["num_reverts"] == ref.numReverts
 
 
+@pytest.mark.parametrize("shape", [(8, 8, 8), (16, 32, 64), (64, 64, 64)])
+def test_constant_bricks_in_a_midrange_set(vr, oracle, shape):
+    """MidRangeTree: constant bricks take the closed form for BOTH streams ([1][3][3] / [0][3][3], all-zero range
+    distances) next to ordinary bricks in one batch; tolerance 0 keeps them on the general path."""
+    z, y, x = shape
+    rng = np.random.default_rng(11)
+    vols = [np.full(shape, 0, np.uint8), rng.integers(0, 256, shape, dtype=np.uint8), np.full(shape, 77, np.uint8),
+            rm_like(shape), np.full(shape, 255, np.uint8)]
+    for tol, ep in ((1, 2), (3, 1), (0, 2)):
+        bs = vr.BrickSet(len(vols), (x, y, z), tol, ep, 2)
+        bs.build(np.stack(vols))
+        dec = bs.decode().cpu().numpy().reshape(len(vols), z, y, x)
+        rdec = bs.decode_range(cut_depth=-1).cpu().numpy().reshape(len(vols), z, y, x)
+        D = bs.info(0)["orig_tree_depth"]
+        rcut = bs.decode_range(cut_depth=max(D - 4, 0)).cpu().numpy().reshape(len(vols), z, y, x)
+        for i, v in enumerate(vols):
+            ref = oracle.OracleTree(v.copy(), tolerance=tol, max_epochs=ep, midrange=True, guarded=True).build()
+            what = (tol, ep, i)
+            assert bs.info(i)["num_active_nodes"] == ref.numActiveNodes and bs.info(i)["num_reverts"] == ref.numReverts, what
+            assert np.array_equal(bs.tree(i), ref.tree) and np.array_equal(bs.tree_range(i), ref.tree_range), what
+            assert list(bs.distance_map(i)) == list(ref.distanceMap), what
+            assert list(bs.distance_map_range(i)) == list(ref.distanceMap_range), what
+            assert np.array_equal(bs.packed4(i), ref.convertToByteArray()), what
+            assert np.array_equal(dec[i], ref.levelCut()) and np.array_equal(rdec[i], ref.levelCutRange(None)), what
+            assert np.array_equal(rcut[i], ref.levelCutRange(max(D - 4, 0))), what
+
+
 def test_guarded_variant_same_bytes(vr, oracle):
     vol = oracle.gen_sphere(32, 7)
     a = vr.BrickSet(1, (32, 32, 32), 1, 3, 0).build(vol.copy())

@@ -37,6 +37,7 @@ struct BrickSet {
     int64_t estSummStride = 0;
     unsigned long long *blockL1 = nullptr; // B * nEmitBlk
     uint8_t *blockFlag = nullptr;          // B * 2^(D-12): kd_encode.hip SkipBlocks (constant / skipped 4096-leaf blocks)
+    uint8_t *blockFlagR = nullptr;         // ... of a MidRangeTree's half-range stream
     uint8_t *blockAlive = nullptr, *blockVal = nullptr;   // B * nEmitBlk
     unsigned long long *blockSpine = nullptr, *blockSpineR = nullptr; // B * nEmitBlk (R: MidRangeTree's range stream)
     uint32_t *chainLut = nullptr;   // 256: grown branch of a leaf by its initial error (k_chain_lut)

@@ -134,7 +134,7 @@ static void free_encoder_buffers(BrickSet &b)
         for (int i = 0; i < 3; ++i) drop(s->recon[i]);
     }
     for (int i = 0; i < 2; ++i) { drop(b.mmMin[i]); drop(b.mmMax[i]); }
-    drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockFlag); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine); drop(b.blockSpineR);
+    drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockFlag); drop(b.blockFlagR); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine); drop(b.blockSpineR);
     drop(b.chainLut); drop(b.blockTot); drop(b.blockOff); drop(b.blockOff64); drop(b.idxBase);
     b.encoderReady = false;
 }
@@ -164,6 +164,7 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
     b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256;
     HIPCHK(hipMalloc(&b.blockL1, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     if (b.D >= 12) HIPCHK(hipMalloc(&b.blockFlag, B * ((size_t)1 << (b.D - 12))));
+    if (b.D >= 12 && b.variant == VR_VARIANT_MIDRANGE) HIPCHK(hipMalloc(&b.blockFlagR, B * ((size_t)1 << (b.D - 12))));
     HIPCHK(hipMalloc(&b.blockAlive, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockVal, B * (size_t)b.nEmitBlk));
     HIPCHK(hipMalloc(&b.blockSpine, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));

@@ -174,7 +174,7 @@ __device__ __forceinline__ uint32_t pk_half_range(vr_s16x2 mn, vr_s16x2 mx) { re
 __global__ void __launch_bounds__(256)
 k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__restrict__ temp, int64_t heapStride,
             uint8_t *__restrict__ tempRange, uint8_t *__restrict__ outMin, uint8_t *__restrict__ outMax,
-            int64_t outStride, uint8_t *__restrict__ blockFlag)
+            int64_t outStride, uint8_t *__restrict__ blockFlag, uint8_t *__restrict__ blockFlagR)
 {
     __shared__ __attribute__((aligned(16))) uint8_t leaf[4096];
     __shared__ uint32_t waveMM[4];
@@ -288,6 +288,7 @@ k_pyramid12(Geom g, Pyr12Geom pg, const uint8_t *__restrict__ vox, uint8_t *__re
         outMax[(int64_t)brick * outStride + (base >> 12)] = (uint8_t)rbm;
         // SkipBlocks: bit 0 = every voxel of the block has one value (the skip bit is set, or not, by the level loop)
         if (blockFlag) blockFlag[(int64_t)brick * ((int64_t)1 << (D - 12)) + (base >> 12)] = ra == rbm ? 1u : 0u;
+        if (blockFlagR) blockFlagR[(int64_t)brick * ((int64_t)1 << (D - 12)) + (base >> 12)] = ra == rbm ? 1u : 0u;   // half ranges all 0
     }
 }
 
@@ -1509,7 +1510,7 @@ struct PruneEmitArgs {
     ReconBufs rbR;
     uint8_t *gap, *gapR;           // the streams' block-gapped buffers (Stream2::tree)
     int64_t treeCap;
-    SkipBlocks sk;                 // blocks the level loop left alone below depth D-2: all "keep", exactly reproduced
+    SkipBlocks sk, skR;            // blocks the level loop left alone below depth D-2: all "keep", exactly reproduced (per stream)
 };
 
 __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
@@ -1573,10 +1574,14 @@ k_prune_emit12(PruneEmitArgs a)
         const Ctrl &cr = a.ctrlsR[brick];
         const int cParR = cr.par;
         upBR = CbR[niU >> 2]; c4BR = CbR[n4 >> 2]; c3BR = CbR[n3 >> 2]; c2BR = CbR[n2 >> 2];
-        c1HR = *(const uint16_t *)(CbR + (n1 >> 2));
-        cpkR = *(const uint32_t *)(CbR + (li >> 2));
-        tvR = *(const uint4 *)(a.tempR + (int64_t)brick * a.heapStride + li);
-        rvR = *(const uint4 *)((cParR == 0 ? a.rbR.b[0] : (cParR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+        // (a block the range stream's level loop skipped: all "keep" and exact there, like the mid stream's above)
+        const bool skipBR = a.skR.flag && (a.skR.flag[(int64_t)brick * a.skR.nBlk + blk] & 2u) != 0u;
+        if (!skipBR) {
+            c1HR = *(const uint16_t *)(CbR + (n1 >> 2));
+            cpkR = *(const uint32_t *)(CbR + (li >> 2));
+            tvR = *(const uint4 *)(a.tempR + (int64_t)brick * a.heapStride + li);
+            rvR = *(const uint4 *)((cParR == 0 ? a.rbR.b[0] : (cParR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+        }
     }
     lutS[t] = lutV; lutS[256 + t] = lutV2;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
@@ -2466,6 +2471,19 @@ k_const_finish(int D, Ctrl *ctrls, uint8_t *tree, int64_t treeCap, uint32_t *idx
     }
 }
 
+// The half-range stream of such a brick (MidRangeTree): every half range is 0, the root's distance 0 and code "keep",
+// the shape the mid stream's (M.cpp:864-865): [0][3][3], or [3] where the mid stream is [3]; distanceMap all zero.
+__global__ void k_const_finish_range(int D, Ctrl *ctrlsR, uint8_t *treeR, int64_t treeCap)
+{
+    Ctrl &c = ctrlsR[blockIdx.x];
+    if (threadIdx.x || !c.constBrick) return;
+    const int v = c.constVal;             // the brick's VALUE (k_ctrl_init): decides the shape only
+    for (int d = 0; d <= D; ++d) c.distanceMap[d] = 0;
+    c.numActive = v ? 3 : 1;
+    *(uint32_t *)(treeR + (int64_t)blockIdx.x * treeCap) = v ? 0x3Cu : 0x03u;
+    c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0; c.statL1 = 0; c.emitOverflow = 0;
+}
+
 // ------------------------------------------------------------ host driver ----
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
@@ -2564,6 +2582,7 @@ int compact_launch(BrickSet *bs, hipStream_t st)
     if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3((unsigned)nblk, B), dim3(64), 0, st, a, bs->rng.tree);
     hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.treeCompact,
                        bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
+    if (mr) hipLaunchKernelGGL(k_const_finish_range, dim3(B), dim3(64), 0, st, D, bs->rng.ctrl, bs->rng.treeCompact, bs->treeCap);
     return launch_status("compact");
 }
 
@@ -2576,7 +2595,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     const bool fused = D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
     // SkipBlocks needs k_pyramid12's constant bit in front and k_prune_emit12 behind, a prune that makes such blocks
     // one token (tolerance >= 1) and a level loop that runs
-    bool skipOn = fused && !mr && bs->blockFlag && bs->tolerance >= 1 && bs->maxEpochs >= 1 && D >= 14 && !getenv("VRHIP_NO_SKIP_BLOCKS");
+    bool skipOn = fused && bs->blockFlag && (!mr || bs->blockFlagR) && bs->tolerance >= 1 && bs->maxEpochs >= 1 && D >= 14 && !getenv("VRHIP_NO_SKIP_BLOCKS");
     const int64_t rootStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
     // ---- BUILD: pyramid.  Bottom 12 levels by k_pyramid12 when x-runs of 16 voxels exist,
     // the rest (and small / thin bricks) in rounds of <= 10 levels.
@@ -2615,7 +2634,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
             pg.spread = bs->spread;
             hipLaunchKernelGGL(k_pyramid12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, bs->g, pg, vox,
                                bs->mid.temp, bs->heapStride, mr ? bs->rng.temp : nullptr, bs->mmMin[0], bs->mmMax[0],
-                               oStride, skipOn ? bs->blockFlag : nullptr);
+                               oStride, skipOn ? bs->blockFlag : nullptr, skipOn && mr ? bs->blockFlagR : nullptr);
             dLeaf = D - 12;
             inMin = bs->mmMin[0]; inMax = bs->mmMax[0]; inStride = oStride;
             rootMinP = inMin; rootMaxP = inMax;
@@ -2643,11 +2662,12 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipEventRecord(bs->ev[1], st);
     dbg_sync(st, "pyramid");
     // ---- COMPRESS
-    // constant bricks take the closed form (VolumeKdtree streams; needs the leaf prune and an epoch to exist)
-    const bool constOk = !mr && bs->maxEpochs >= 1 && bs->tolerance >= 1 && D >= 1;
+    // constant bricks take the closed form (both streams of a MidRangeTree too; needs the leaf prune and an epoch to exist)
+    const bool constOk = bs->maxEpochs >= 1 && bs->tolerance >= 1 && D >= 1;
     const SkipBlocks sk{skipOn ? bs->blockFlag : nullptr, (int64_t)1 << (D >= 12 ? D - 12 : 0), D - 2};
     compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk);
-    if (mr) compress_stream(bs, bs->rng, st, nullptr, nullptr, 0, SkipBlocks{nullptr, 0, 0});
+    const SkipBlocks skR{skipOn && mr ? bs->blockFlagR : nullptr, sk.nBlk, D - 2};
+    if (mr) compress_stream(bs, bs->rng, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, skR);
     hipEventRecord(bs->ev[2], st);
     dbg_sync(st, "compress");
     // ---- PRUNE
@@ -2658,7 +2678,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     bs->fineHas.assign((size_t)B, 0);
     if (fused) {
         PruneEmitArgs pa;
-        pa.sk = sk;
+        pa.sk = sk; pa.skR = skR;
         pa.D = D; pa.tol = bs->tolerance; pa.maxDepth = bs->maxDepth; pa.ctrls = bs->mid.ctrl;
         pa.temp = bs->mid.temp; pa.codes = bs->mid.codes;
         pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->leafStride;
@@ -2720,6 +2740,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_emit_stats, dim3(B), dim3(1024), 0, st, a, (int64_t)(D >= 12 ? cdiv((int64_t)1 << D, 1024) : cdiv((int64_t)1 << D, 256)));
     hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.tree,
                        bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
+    if (mr) hipLaunchKernelGGL(k_const_finish_range, dim3(B), dim3(64), 0, st, D, bs->rng.ctrl, bs->rng.tree, bs->treeCap);
     hipEventRecord(bs->ev[4], st);
     dbg_sync(st, "emit_write");
     return launch_status("encode");
