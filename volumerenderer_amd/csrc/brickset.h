@@ -80,6 +80,12 @@ struct BrickSet {
     bool foreign = false;       // stream installed by set_tree/open (no encoder state)
     std::vector<int64_t> openTreeBytes; // per brick: tree.bits size as the reference's open() would have it
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // MidRangeTree: the half-range stream's level loop runs on a stream of its own beside the mid stream's (fork / join
+    // by events around the two compress_stream calls), with its own partial-sum and estimator scratch
+    hipStream_t aux = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    unsigned long long *blockErrR = nullptr;
+    void *estSummR = nullptr;
     float phasesMs[5] = {0, 0, 0, 0, 0};
     bool timingsPending = false, decodeTimingPending = false;
     void *lastStream = nullptr;

@@ -134,7 +134,7 @@ static void free_encoder_buffers(BrickSet &b)
         for (int i = 0; i < 3; ++i) drop(s->recon[i]);
     }
     for (int i = 0; i < 2; ++i) { drop(b.mmMin[i]); drop(b.mmMax[i]); }
-    drop(b.blockErr); drop(b.estSumm); drop(b.blockL1); drop(b.blockFlag); drop(b.blockFlagR); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine); drop(b.blockSpineR);
+    drop(b.blockErr); drop(b.estSumm); drop(b.blockErrR); drop(b.estSummR); drop(b.blockL1); drop(b.blockFlag); drop(b.blockFlagR); drop(b.blockAlive); drop(b.blockVal); drop(b.blockSpine); drop(b.blockSpineR);
     drop(b.chainLut); drop(b.blockTot); drop(b.blockOff); drop(b.blockOff64); drop(b.idxBase);
     b.encoderReady = false;
 }
@@ -161,6 +161,10 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.blockErr, B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
     b.estSummStride = ((int64_t)1 << b.D) / 1024 > 0 ? ((int64_t)1 << b.D) / 1024 : 1;
     HIPCHK(hipMalloc(&b.estSumm, B * (size_t)b.estSummStride * 128));
+    if (b.variant == VR_VARIANT_MIDRANGE) {
+        HIPCHK(hipMalloc(&b.blockErrR, B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&b.estSummR, B * (size_t)b.estSummStride * 128));
+    }
     b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256;
     HIPCHK(hipMalloc(&b.blockL1, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
     if (b.D >= 12) HIPCHK(hipMalloc(&b.blockFlag, B * ((size_t)1 << (b.D - 12))));
@@ -200,6 +204,9 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_stream2(b.rng);
     hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.idxVal3); hipFree(b.chainTab); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread); hipFree(b.srcIdx); hipFree(b.ownerRank); hipFree(b.ownerSurv); hipFree(b.rankVals);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
+    if (b.evFork) hipEventDestroy(b.evFork);
+    if (b.evJoin) hipEventDestroy(b.evJoin);
+    if (b.aux) hipStreamDestroy(b.aux);
     delete h;
     return VR_OK;
 }
@@ -279,6 +286,11 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
             e = hipMemcpy(b.spread, sp.data(), sp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
         for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&b.ev[i]);
+        if (e == hipSuccess && b.variant == VR_VARIANT_MIDRANGE) {
+            e = hipStreamCreateWithFlags(&b.aux, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evFork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evJoin, hipEventDisableTiming);
+        }
         if (e != hipSuccess) rc = e == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
     }
     if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }

@@ -2488,7 +2488,7 @@ __global__ void k_const_finish_range(int D, Ctrl *ctrlsR, uint8_t *treeR, int64_
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint8_t *rootMin, const uint8_t *rootMax,
-                            int64_t mmStride, SkipBlocks sk)
+                            int64_t mmStride, SkipBlocks sk, unsigned long long *blockErr, void *estSumm)
 {
     const int D = bs->D, B = bs->B;
     ReconBufs rb{{s.recon[0], s.recon[1], s.recon[2]}};
@@ -2508,21 +2508,21 @@ static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint
                 const int nc = r < 2 ? 4 : EST_CAND, ncNext = r + 1 < 2 ? 4 : EST_CAND;   // two 4-wide windows, then 8-wide ones
                 const unsigned gx = r == 0 ? cdiv(nseg, 16) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);   // four segments per wave first
                 hipLaunchKernelGGL(k_est_summ, dim3(gx, B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
-                                   bs->heapStride, rb, bs->leafStride, (uint32_t *)bs->estSumm, bs->estSummStride, sk);
+                                   bs->heapStride, rb, bs->leafStride, (uint32_t *)estSumm, bs->estSummStride, sk);
                 hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, ncNext,
                                    r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
-                                   (const uint32_t *)bs->estSumm, bs->estSummStride, sk);
+                                   (const uint32_t *)estSumm, bs->estSummStride, sk);
             }
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
                 hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, bs->maxEpochs, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk, sk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, blockErr, bs->nErrBlk, sk);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, blockErr, bs->nErrBlk);
             hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, guarded, s.ctrl, s.temp,
-                               bs->heapStride, rb, bs->leafStride, bs->blockErr, bs->nErrBlk);
+                               bs->heapStride, rb, bs->leafStride, blockErr, bs->nErrBlk);
         }
         hipLaunchKernelGGL(k_level_end, dim3(B), dim3(64), 0, st, d, s.ctrl);
     }
@@ -2665,9 +2665,22 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // constant bricks take the closed form (both streams of a MidRangeTree too; needs the leaf prune and an epoch to exist)
     const bool constOk = bs->maxEpochs >= 1 && bs->tolerance >= 1 && D >= 1;
     const SkipBlocks sk{skipOn ? bs->blockFlag : nullptr, (int64_t)1 << (D >= 12 ? D - 12 : 0), D - 2};
-    compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk);
     const SkipBlocks skR{skipOn && mr ? bs->blockFlagR : nullptr, sk.nBlk, D - 2};
-    if (mr) compress_stream(bs, bs->rng, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, skR);
+    // MidRangeTree: the two streams' level loops do not depend on each other (M.cpp:399-544 runs them one after the
+    // other): the half-range stream's goes to the set's second stream, so its one-wave-per-brick walkers run beside
+    // the mid stream's wide kernels and the other way round
+    const bool forkR = mr && bs->aux && bs->blockErrR && bs->estSummR && !getenv("VRHIP_MR_SERIAL");
+    if (forkR) {
+        hipEventRecord(bs->evFork, st);
+        hipStreamWaitEvent(bs->aux, bs->evFork, 0);
+        compress_stream(bs, bs->rng, bs->aux, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, skR,
+                        bs->blockErrR, bs->estSummR);
+        hipEventRecord(bs->evJoin, bs->aux);
+    }
+    compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk, bs->blockErr, bs->estSumm);
+    if (forkR) hipStreamWaitEvent(st, bs->evJoin, 0);
+    else if (mr) compress_stream(bs, bs->rng, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, skR,
+                                 bs->blockErr, bs->estSumm);
     hipEventRecord(bs->ev[2], st);
     dbg_sync(st, "compress");
     // ---- PRUNE
