@@ -371,6 +371,9 @@ def main():
     while True:
         try:
             sets = [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
+            if NS >= 2:                # several sets in flight fill each other's gaps: no fork inside a build (vrhip.h)
+                for s_ in sets:
+                    s_.set_concurrency(1)
             for s_ in sets:            # setup, not a step: allocate and first-touch every set's buffers
                 s_.build(vox); s_.decode(out)
             torch.cuda.synchronize()
@@ -433,6 +436,7 @@ def main():
 
     # per-kernel timing outside the timed region, strictly serial: hipEvents on the launch stream
     # (vr_brickset_last_timings)
+    bs.set_concurrency(2)              # the library's default: what a single build() call gets
     enc_ms, dec_ms = [], []
     for i in range(4):
         bs.build(vox)
@@ -479,6 +483,7 @@ def main():
                                                                          args.max_epochs),
                       "pipeline": ("%d bricksets in flight, each on its own stream: build + levelCut of step k run "
                                    "beside those of the following steps" % NS if NS >= 2 else "serial"),
+                      "level_loop_streams": {"pipelined": 1 if NS >= 2 else 2, "serial": 2},
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},

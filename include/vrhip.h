@@ -249,6 +249,15 @@ vr_status vr_composite_slabs(const float *partials_dev, int32_t num_slabs, int64
  * phases[0..4] = BUILD(pyramid), COMPRESS, PRUNE, CONVERT, DECODE. */
 vr_status vr_brickset_last_timings(vr_brickset *bs, float phases_ms[5]);
 
+/* ---- concurrency inside one build (new; the reference's build(useThreads) is its nearest relative, R.cpp:17) ----
+ * The level loop (compressGradientDescent) of a VolumeKdtree set is a chain of wide kernels and of one-wave-per-brick
+ * control steps; run over `level_loop_streams` ranges of the bricks side by side (internal streams, forked from and
+ * joined to the call's stream by events) the control steps of one range hide behind the wide kernels of another.
+ * 1 = off, 2 = default, up to 4.  One build alone on the device: 2 is 5 % and 4 is 8 % faster than 1; with several
+ * bricksets in flight on streams of their own, 1 is the right choice (the sets already fill each other's gaps).
+ * Results do not depend on it.  MidRangeTree sets always run their two streams' level loops side by side. */
+vr_status vr_brickset_set_concurrency(vr_brickset *bs, int32_t level_loop_streams);
+
 #ifdef __cplusplus
 }
 #endif

@@ -705,3 +705,30 @@ def test_midrange_range_decode_below_pruned_blocks(vr, oracle):
         for cut in (None, D, D - 3, D - 6, D - 7, D - 12, 4):
             got = bs.decode_range(cut_depth=-1 if cut is None else cut).cpu().numpy().reshape(vol.shape)
             assert np.array_equal(got, ref.levelCutRange(cut)), (name, cut)
+
+
+def test_level_loop_concurrency_does_not_change_results(vr, oracle):
+    """vr_brickset_set_concurrency: the level loops of 1 / 2 / 4 brick ranges side by side on internal streams give the
+    same streams (and the oracle's), also with constant bricks at range boundaries and for repeated builds."""
+    rng = np.random.default_rng(21)
+    shape = (16, 32, 32)
+    z, y, x = shape
+    vols = []
+    for i in range(70):
+        k = i % 5
+        vols.append(np.full(shape, (i * 37) & 255, np.uint8) if k == 4 else (rm_like(shape, i) if k == 3 else rng.integers(0, 256, shape, dtype=np.uint8)))
+    stack = np.stack(vols)
+    got = {}
+    for n in (1, 2, 4, 3):
+        bs = vr.BrickSet(len(vols), (x, y, z), 1, 2).set_concurrency(n)
+        for _ in range(2):
+            bs.build(stack)
+        got[n] = [bs.tree(i).tobytes() for i in range(len(vols))], [tuple(bs.distance_map(i)) for i in range(len(vols))], \
+            bs.decode().cpu().numpy().copy()
+    for n in (2, 4, 3):
+        assert got[n][0] == got[1][0] and got[n][1] == got[1][1] and np.array_equal(got[n][2], got[1][2]), n
+    for i in (0, 4, 17, 34, 35, 52, 69):
+        ref = oracle.OracleTree(vols[i].copy(), tolerance=1, max_epochs=2).build()
+        assert got[2][0][i] == ref.tree.tobytes() and list(got[2][1][i]) == list(ref.distanceMap)
+    with pytest.raises(vr.VrError):
+        vr.BrickSet(1, (x, y, z), 1, 2).set_concurrency(5)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vr_composite_finish": (_I32, [_P, _P, _I64, _P]),
     "vr_composite_slabs": (_I32, [_P, _I32, _I64, _I64, _I32, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
     "vr_brickset_last_timings": (_I32, [_P, C.POINTER(C.c_float)]),
+    "vr_brickset_set_concurrency": (_I32, [_P, C.c_int32]),
 }
 
 _lib = None

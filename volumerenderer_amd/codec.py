@@ -147,6 +147,11 @@ class BrickSet:
         check(L.vr_brickset_info(h, 0, C.byref(ti)), "vr_brickset_info")
         return cls(1, (ti.X, ti.Y, ti.Z), _handle=h)
 
+    def set_concurrency(self, level_loop_streams):
+        """Brick ranges whose level loops run side by side inside one build (1 = off, 2 = default, <= 4): see vrhip.h."""
+        check(self._L.vr_brickset_set_concurrency(self._h, int(level_loop_streams)), "set_concurrency")
+        return self
+
     def last_timings(self):
         ms = (C.c_float * 5)()
         check(self._L.vr_brickset_last_timings(self._h, ms), "last_timings")

@@ -82,8 +82,9 @@ struct BrickSet {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // MidRangeTree: the half-range stream's level loop runs on a stream of its own beside the mid stream's (fork / join
     // by events around the two compress_stream calls), with its own partial-sum and estimator scratch
-    hipStream_t aux = nullptr;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t aux = nullptr, auxN[3] = {nullptr, nullptr, nullptr};     // aux == auxN[0]
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evJoinN[3] = {nullptr, nullptr, nullptr};
+    int levelLoopStreams = 2;      // VolumeKdtree: brick ranges whose level loops run side by side (1 = none); vr_brickset_set_concurrency
     unsigned long long *blockErrR = nullptr;
     void *estSummR = nullptr;
     float phasesMs[5] = {0, 0, 0, 0, 0};

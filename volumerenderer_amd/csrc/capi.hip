@@ -205,8 +205,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.idxVal3); hipFree(b.chainTab); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread); hipFree(b.srcIdx); hipFree(b.ownerRank); hipFree(b.ownerSurv); hipFree(b.rankVals);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     if (b.evFork) hipEventDestroy(b.evFork);
-    if (b.evJoin) hipEventDestroy(b.evJoin);
-    if (b.aux) hipStreamDestroy(b.aux);
+    for (int i = 0; i < 3; ++i) { if (b.evJoinN[i]) hipEventDestroy(b.evJoinN[i]); if (b.auxN[i]) hipStreamDestroy(b.auxN[i]); }
     delete h;
     return VR_OK;
 }
@@ -286,11 +285,12 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
             e = hipMemcpy(b.spread, sp.data(), sp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
         for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&b.ev[i]);
-        if (e == hipSuccess && b.variant == VR_VARIANT_MIDRANGE) {
-            e = hipStreamCreateWithFlags(&b.aux, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evFork, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evJoin, hipEventDisableTiming);
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+            e = hipStreamCreateWithFlags(&b.auxN[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evJoinN[i], hipEventDisableTiming);
         }
+        b.aux = b.auxN[0]; b.evJoin = b.evJoinN[0];
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evFork, hipEventDisableTiming);
         if (e != hipSuccess) rc = e == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
     }
     if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }
@@ -835,6 +835,13 @@ vr_status vr_composite_slabs(const float *partials, int32_t num_slabs, int64_t n
     if (!device_ok()) return VR_ERR_NO_DEVICE;
     return composite_slabs_launch(partials, num_slabs, num_pixels, first_pixel, axis, cam, P, rgba, (hipStream_t)stream) == 0
                ? VR_OK : VR_ERR_NO_DEVICE;
+}
+
+vr_status vr_brickset_set_concurrency(vr_brickset *h, int32_t level_loop_streams)
+{
+    if (!h || level_loop_streams < 1 || level_loop_streams > 4) return VR_ERR_INVALID;
+    h->s.levelLoopStreams = level_loop_streams;
+    return VR_OK;
 }
 
 vr_status vr_brickset_last_timings(vr_brickset *h, float ms[5])

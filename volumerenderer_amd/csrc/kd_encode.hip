@@ -2487,10 +2487,20 @@ __global__ void k_const_finish_range(int D, Ctrl *ctrlsR, uint8_t *treeR, int64_
 // ------------------------------------------------------------ host driver ----
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-static void compress_stream(BrickSet *bs, Stream2 &s, hipStream_t st, const uint8_t *rootMin, const uint8_t *rootMax,
-                            int64_t mmStride, SkipBlocks sk, unsigned long long *blockErr, void *estSumm)
+// The level loop of the bricks [b0, b0 + nb) of a stream (every array of a set is per brick: a sub-range is the same
+// launches on offset pointers)
+static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uint8_t *rootMin, const uint8_t *rootMax,
+                            int64_t mmStride, SkipBlocks sk, unsigned long long *blockErr, void *estSumm0,
+                            int b0 = 0, int nb = -1)
 {
-    const int D = bs->D, B = bs->B;
+    const int D = bs->D, B = nb < 0 ? bs->B : nb;
+    struct { Ctrl *ctrl; uint8_t *temp, *codes; uint8_t *recon[3]; } s;
+    s.ctrl = s0.ctrl + b0; s.temp = s0.temp + (int64_t)b0 * bs->heapStride; s.codes = s0.codes + (int64_t)b0 * bs->codeStride;
+    for (int i = 0; i < 3; ++i) s.recon[i] = s0.recon[i] + (int64_t)b0 * bs->leafStride;
+    blockErr += (int64_t)b0 * bs->nErrBlk;
+    void *estSumm = (uint32_t *)estSumm0 + (int64_t)b0 * bs->estSummStride * (4 * EST_CAND);
+    if (sk.flag) sk.flag += (int64_t)b0 * sk.nBlk;
+    if (rootMin) { rootMin += (int64_t)b0 * mmStride; rootMax += (int64_t)b0 * mmStride; }
     ReconBufs rb{{s.recon[0], s.recon[1], s.recon[2]}};
     const int guarded = bs->variant != 0; // GUARDED and MIDRANGE both carry the :333/:340 guard
     hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl, rootMin, rootMax, mmStride);
@@ -2677,6 +2687,24 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
                         bs->blockErrR, bs->estSummR);
         hipEventRecord(bs->evJoin, bs->aux);
     }
+    // VolumeKdtree: the same trick over ranges of the bricks (vr_brickset_set_concurrency; 2 by default)
+    int parts = bs->levelLoopStreams;
+    if (const char *e = getenv("VRHIP_FORK_BRICKS")) parts = atoi(e);
+    if (mr || !bs->aux || B < 16 * parts || parts < 2) parts = 1;
+    if (parts > 4) parts = 4;
+    if (parts > 1) {
+        hipEventRecord(bs->evFork, st);
+        for (int p = 1; p < parts; ++p) {
+            const int b0 = (int)((int64_t)B * p / parts), b1 = (int)((int64_t)B * (p + 1) / parts);
+            hipStreamWaitEvent(bs->auxN[p - 1], bs->evFork, 0);
+            compress_stream(bs, bs->mid, bs->auxN[p - 1], constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk,
+                            bs->blockErr, bs->estSumm, b0, b1 - b0);
+            hipEventRecord(bs->evJoinN[p - 1], bs->auxN[p - 1]);
+        }
+        compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk, bs->blockErr,
+                        bs->estSumm, 0, (int)((int64_t)B / parts));
+        for (int p = 1; p < parts; ++p) hipStreamWaitEvent(st, bs->evJoinN[p - 1], 0);
+    } else
     compress_stream(bs, bs->mid, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, sk, bs->blockErr, bs->estSumm);
     if (forkR) hipStreamWaitEvent(st, bs->evJoin, 0);
     else if (mr) compress_stream(bs, bs->rng, st, constOk ? rootMinP : nullptr, constOk ? rootMaxP : nullptr, rootStride, skR,
