@@ -314,6 +314,9 @@ def main():
                          "each of the 288 GB): build + levelCut of steps k, k+1, k+2 run beside each other (the streaming "
                          "use: the next timesteps compress while this one decodes; falls back to 2 if the third set "
                          "does not fit); 1: strictly serial")
+    ap.add_argument("--level-loop-streams", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="vr_brickset_set_concurrency for the strictly serial pass (library default 2; 1 for clean "
+                         "per-kernel profiles).  The pipelined sets always use 1")
     ap.add_argument("--composite", action="store_true",
                     help="N > 1 only: also time a sort-last composited 1080p frame over RCCL (off by default: a "
                          "collective that fails on one rank must never hang the headline measurement)")
@@ -371,9 +374,8 @@ def main():
     while True:
         try:
             sets = [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
-            if NS >= 2:                # several sets in flight fill each other's gaps: no fork inside a build (vrhip.h)
-                for s_ in sets:
-                    s_.set_concurrency(1)
+            for s_ in sets:            # several sets in flight fill each other's gaps: no fork inside a build (vrhip.h)
+                s_.set_concurrency(1 if NS >= 2 else args.level_loop_streams)
             for s_ in sets:            # setup, not a step: allocate and first-touch every set's buffers
                 s_.build(vox); s_.decode(out)
             torch.cuda.synchronize()
@@ -436,7 +438,7 @@ def main():
 
     # per-kernel timing outside the timed region, strictly serial: hipEvents on the launch stream
     # (vr_brickset_last_timings)
-    bs.set_concurrency(2)              # the library's default: what a single build() call gets
+    bs.set_concurrency(args.level_loop_streams)      # default 2 = the library's: what a single build() call gets
     enc_ms, dec_ms = [], []
     for i in range(4):
         bs.build(vox)
@@ -483,7 +485,7 @@ def main():
                                                                          args.max_epochs),
                       "pipeline": ("%d bricksets in flight, each on its own stream: build + levelCut of step k run "
                                    "beside those of the following steps" % NS if NS >= 2 else "serial"),
-                      "level_loop_streams": {"pipelined": 1 if NS >= 2 else 2, "serial": 2},
+                      "level_loop_streams": {"pipelined": 1 if NS >= 2 else args.level_loop_streams, "serial": args.level_loop_streams},
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
