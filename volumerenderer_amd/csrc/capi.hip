@@ -285,12 +285,7 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
             e = hipMemcpy(b.spread, sp.data(), sp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         }
         for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&b.ev[i]);
-        for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-            e = hipStreamCreateWithFlags(&b.auxN[i], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evJoinN[i], hipEventDisableTiming);
-        }
-        b.aux = b.auxN[0]; b.evJoin = b.evJoinN[0];
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.evFork, hipEventDisableTiming);
+        // (the internal streams of a build are created when a build first needs them: kd_encode.hip ensure_aux)
         if (e != hipSuccess) rc = e == hipErrorOutOfMemory ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
     }
     if (rc != VR_OK) { vr_brickset_destroy(h); return rc; }

@@ -2596,6 +2596,24 @@ int compact_launch(BrickSet *bs, hipStream_t st)
     return launch_status("compact");
 }
 
+// Internal streams for the forks below, created on first need and only as many as are used: a process has few hardware
+// queues (4 by default), streams beyond them share one, and a kernel queued behind another stream's long copy on a shared
+// queue waits for it (a MidRangeTree build inside the timestep streamer took 236 instead of 68 ms with three idle
+// extra streams per handle).
+static int ensure_aux(BrickSet *bs, int n)
+{
+    if (n > 3) n = 3;
+    if (!bs->evFork && hipEventCreateWithFlags(&bs->evFork, hipEventDisableTiming) != hipSuccess) return 0;
+    int have = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!bs->auxN[i] && hipStreamCreateWithFlags(&bs->auxN[i], hipStreamNonBlocking) != hipSuccess) break;
+        if (!bs->evJoinN[i] && hipEventCreateWithFlags(&bs->evJoinN[i], hipEventDisableTiming) != hipSuccess) break;
+        ++have;
+    }
+    bs->aux = bs->auxN[0]; bs->evJoin = bs->evJoinN[0];
+    return have;
+}
+
 int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
 {
     const int D = bs->D, B = bs->B;
@@ -2679,7 +2697,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // MidRangeTree: the two streams' level loops do not depend on each other (M.cpp:399-544 runs them one after the
     // other): the half-range stream's goes to the set's second stream, so its one-wave-per-brick walkers run beside
     // the mid stream's wide kernels and the other way round
-    const bool forkR = mr && bs->aux && bs->blockErrR && bs->estSummR && !getenv("VRHIP_MR_SERIAL");
+    const bool forkR = mr && bs->blockErrR && bs->estSummR && !getenv("VRHIP_MR_SERIAL") && ensure_aux(bs, 1) == 1;
     if (forkR) {
         hipEventRecord(bs->evFork, st);
         hipStreamWaitEvent(bs->aux, bs->evFork, 0);
@@ -2690,8 +2708,9 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // VolumeKdtree: the same trick over ranges of the bricks (vr_brickset_set_concurrency; 2 by default)
     int parts = bs->levelLoopStreams;
     if (const char *e = getenv("VRHIP_FORK_BRICKS")) parts = atoi(e);
-    if (mr || !bs->aux || B < 16 * parts || parts < 2) parts = 1;
     if (parts > 4) parts = 4;
+    if (mr || B < 16 * parts || parts < 2) parts = 1;
+    if (parts > 1) parts = 1 + ensure_aux(bs, parts - 1);
     if (parts > 1) {
         hipEventRecord(bs->evFork, st);
         for (int p = 1; p < parts; ++p) {
