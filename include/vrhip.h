@@ -102,7 +102,9 @@ vr_status vr_download(void *dst_host, const void *src_dev, int64_t bytes, void *
  * corner of a box of several cells, R.cpp:194-195, and levelCut's boxes that leave some voxels unwritten,
  * R.cpp:759-766 with 806-833; all reproduced bit for bit).  Power-of-two extents up to 1024 per axis (the
  * reference's brick sizes 256x256x128 / 256^3) take the tiled fast kernels, everything else table-driven ones.
- * Limits of one tree: origTreeDepth <= 28 and fewer than 2^31 voxels -> VR_ERR_UNSUPPORTED beyond. */
+ * Limits of one tree: origTreeDepth <= 31, fewer than 2^32 voxels and at most 2^20 cells per axis; deeper than 28
+ * levels (a stream can then pass 2^32 tokens: 64-bit token offsets, table-driven kernels) only with num_bricks == 1
+ * -> VR_ERR_UNSUPPORTED beyond.  The reference program's own 2048x2048x768 tree (main.cpp:242-251) is 31 levels. */
 vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_t dims[3],
                              int32_t tolerance, int32_t max_epochs, int32_t variant);
 vr_status vr_brickset_destroy(vr_brickset *bs);
@@ -257,6 +259,18 @@ vr_status vr_brickset_last_timings(vr_brickset *bs, float phases_ms[5]);
  * bricksets in flight on streams of their own, 1 is the right choice (the sets already fill each other's gaps).
  * Results do not depend on it.  MidRangeTree sets always run their two streams' level loops side by side. */
 vr_status vr_brickset_set_concurrency(vr_brickset *bs, int32_t level_loop_streams);
+
+/* ---- debugging switches (new) ----------------------------------------------------------------------------------
+ * Which kernel serves a call is decided by the set's geometry and by a few switches kept IN THE HANDLE: they are
+ * initialised from the environment (VRHIP_DECODE_WALK, VRHIP_DECODE_FINE_V1, VRHIP_DECODE_QUAD, VRHIP_DECODE_V1,
+ * VRHIP_NO_FUSED_EMIT, VRHIP_NO_SKIP_BLOCKS, VRHIP_NOSWZ, VRHIP_MR_SERIAL, VRHIP_FORK_BRICKS) once, when the set is
+ * created, and changed afterwards only through this call -- never by the environment at launch time.  Names:
+ * "decode_walk", "decode_fine_v1", "decode_quad", "decode_v1", "no_skip_blocks", "noswz", "mr_serial",
+ * "fork_bricks" (0..4), "no_fused_emit" (before the first build only: VR_ERR_STATE afterwards).  Results never
+ * depend on a switch; the tests use them to check the kernels against each other.
+ * vr_debug_set: process-wide switches that belong to no set: "skip_grid_v1". */
+vr_status vr_brickset_set_switch(vr_brickset *bs, const char *name, int32_t value);
+vr_status vr_debug_set(const char *name, int32_t value);
 
 #ifdef __cplusplus
 }

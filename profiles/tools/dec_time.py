@@ -1,4 +1,6 @@
-"""decode-only timing on the bench volume: python profiles/tools/dec_time.py [nbricks]"""
+"""decode-only timing on the bench volume: python profiles/tools/dec_time.py [nbricks]
+times the default kernel (k_decode_region) and, unless QUICK=1, round 2's k_decode_quad and round 1's k_decode_fine
+on the same set (vr_brickset_set_switch), and checks that they agree"""
 import sys, os, time
 sys.path.insert(0, "/root/repo")
 import __graft_entry__ as g
@@ -25,8 +27,12 @@ def run(tag):
     for i in range(6):
         bs.decode(out); torch.cuda.synchronize(); ms.append(bs.last_timings()["DECODE"])
     print("%-10s decode ms min %.3f med %.3f  -> %.0f GB/s (frac %.3f)" % (tag, min(ms), sorted(ms)[3], alg / min(ms) / 1e6, alg / min(ms) / 1e6 / 8000), flush=True)
-    return out.clone() if B <= 64 else None
-run(os.environ.get("TAG", "quad"))
-os.environ["VRHIP_DECODE_FINE_V1"] = "1"
-run("fine_v1")
-del os.environ["VRHIP_DECODE_FINE_V1"]
+    return out.clone()
+ref = run(os.environ.get("TAG", "region"))
+if os.environ.get("QUICK") != "1":
+    for name in ("decode_quad", "decode_fine_v1"):
+        bs.set_switch(name, 1)
+        o = run(name)
+        bs.set_switch(name, 0)
+        print("   equal to the default kernel's output:", bool(torch.equal(o, ref)), flush=True)
+        del o

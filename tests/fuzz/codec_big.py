@@ -27,9 +27,9 @@ for it in range(n):
           and np.array_equal(bs.decode().cpu().numpy().reshape(shape), ref.levelCut()))
     if ok:
         import os
-        os.environ["VRHIP_DECODE_WALK"] = "1"
+        bs.set_switch("decode_walk", 1)
         ok = np.array_equal(bs.decode().cpu().numpy().reshape(shape), ref.levelCut())
-        del os.environ["VRHIP_DECODE_WALK"]
+        bs.set_switch("decode_walk", 0)
         fs = vr.BrickSet(1, (x, y, z), tol, ep, var)
         fs.set_tree(0, ref.tree, ref.numActiveNodes, ref.distanceMap)
         ok = ok and np.array_equal(fs.decode().cpu().numpy().reshape(shape), ref.levelCut())

@@ -469,6 +469,46 @@ def _mixed_volume(rng, shape):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
+@pytest.mark.parametrize("shape", [(64, 128, 128), (128, 128, 256), (128, 128, 128), (16, 16, 128), (64, 256, 256)])
+def test_region_decode_all_axis_orders(vr, oracle, shape):
+    """k_decode_region (a wave per 16^3 emit block, a workgroup per 128 x 16 x 16 region) wherever the twelve deepest
+    levels are four equal (a, b, c) triples: x second in a triple (the bench's 256 x 256 x 128 shape), x deepest
+    (256 x 128 x 128), x first (cubes).  Against the oracle's levelCut / levelCutProgressive at every cut the kernel
+    serves, against round 2's k_decode_quad and the walking k_decode_tile, on volumes with pruned regions of every
+    size next to long grown branches, with several bricks per launch.  (16, 16, 128) does not qualify and must
+    still decode (the older kernels)."""
+    rng = np.random.default_rng(4000 + shape[0] + shape[2])
+    z, y, x = shape
+    vols = [rm_like(shape, 5), _mixed_volume(rng, shape), _mixed_volume(rng, shape)]
+    vols.append(np.full(shape, 77, np.uint8))                                    # a constant brick inside the batch
+    vols.append(rng.integers(0, 256, shape, dtype=np.uint8) if z * y * x <= (1 << 21) else _mixed_volume(rng, shape))
+    tol, ep = (1, 2) if shape[0] != 128 else (2, 3)
+    bs = vr.BrickSet(len(vols), (x, y, z), tol, ep)
+    bs.build(np.stack(vols))
+    refs = [oracle.OracleTree(v.copy(), tolerance=tol, max_epochs=ep).build() for v in vols]
+    D, M = refs[0].origTreeDepth, refs[0].maxTreeDepth
+    for b, ref in enumerate(refs):
+        assert np.array_equal(bs.tree(b), ref.tree), b
+    for cut in [None, M - 1, D + 4, D + 1, D, D - 1, D - 2, D - 3]:
+        got = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape((len(vols),) + shape)
+        bs.set_switch("decode_quad", 1)
+        quad = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape((len(vols),) + shape)
+        bs.set_switch("decode_quad", 0)
+        assert np.array_equal(got, quad), cut
+        for b, ref in enumerate(refs):
+            want = ref.levelCut() if cut is None else ref.levelCutProgressive(cut)
+            assert np.array_equal(got[b], want), (b, cut)
+    bs.set_switch("decode_walk", 1)
+    walk = bs.decode().cpu().numpy().reshape((len(vols),) + shape)
+    bs.set_switch("decode_walk", 0)
+    assert np.array_equal(walk, bs.decode().cpu().numpy().reshape((len(vols),) + shape))
+    # the same bytes as a foreign stream (open()): contiguous layout, side-cars from the host parse of the bytes
+    fs = vr.BrickSet(1, (x, y, z), tol, ep)
+    fs.set_tree(0, refs[1].tree, refs[1].numActiveNodes, refs[1].distanceMap)
+    assert np.array_equal(fs.decode().cpu().numpy().reshape(shape), refs[1].levelCut())
+    assert np.array_equal(fs.decode(cut_depth=D - 2).cpu().numpy().reshape(shape), refs[1].levelCutProgressive(D - 2))
+
+
 @pytest.mark.parametrize("shape", [(4, 8, 128), (8, 16, 128), (16, 16, 256), (8, 8, 512)])
 def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shape):
     """k_decode_fine (one lane per four voxels, token offsets from the fused encoder's per-4-leaf counts) against
@@ -491,12 +531,12 @@ def test_fine_decode_equals_walk_decode_and_oracle(vr, oracle, monkeypatch, shap
             want = ref.levelCut() if cut is None else ref.levelCutProgressive(cut)
             # default: k_decode_quad for cuts >= D-3 (one table lookup per voxel leaf), k_decode_fine above
             quad = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
-            monkeypatch.setenv("VRHIP_DECODE_FINE_V1", "1")
+            bs.set_switch("decode_fine_v1", 1)
             fine = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
-            monkeypatch.delenv("VRHIP_DECODE_FINE_V1")
-            monkeypatch.setenv("VRHIP_DECODE_WALK", "1")
+            bs.set_switch("decode_fine_v1", 0)
+            bs.set_switch("decode_walk", 1)
             walk = (bs.decode() if cut is None else bs.decode(cut_depth=cut)).cpu().numpy().reshape(shape)
-            monkeypatch.delenv("VRHIP_DECODE_WALK")
+            bs.set_switch("decode_walk", 0)
             assert np.array_equal(quad, want), (case, tol, ep, cut)
             assert np.array_equal(fine, want), (case, tol, ep, cut)
             assert np.array_equal(walk, want), (case, tol, ep, cut)

@@ -32,16 +32,21 @@ def test_full_volume_properties(oracle, monkeypatch):
     bs.build(vox)
     fine = bs.decode()
     # 1. the lane-per-four-voxels decode and the walking decode agree on all 8 G voxels; decoding is idempotent
-    monkeypatch.setenv("VRHIP_DECODE_WALK", "1")
+    bs.set_switch("decode_walk", 1)
     walk = bs.decode()
-    monkeypatch.delenv("VRHIP_DECODE_WALK")
+    bs.set_switch("decode_walk", 0)
     assert torch.equal(fine, walk)
     del walk
-    monkeypatch.setenv("VRHIP_DECODE_FINE_V1", "1")       # ... and so does the round-1 fine kernel (k_decode_quad is the default)
+    bs.set_switch("decode_fine_v1", 1)       # ... and so do the round-1 fine kernel
     v1 = bs.decode()
-    monkeypatch.delenv("VRHIP_DECODE_FINE_V1")
+    bs.set_switch("decode_fine_v1", 0)
     assert torch.equal(fine, v1)
     del v1
+    bs.set_switch("decode_quad", 1)          # ... and round 2's tile kernel (k_decode_region is the default)
+    v2 = bs.decode()
+    bs.set_switch("decode_quad", 0)
+    assert torch.equal(fine, v2)
+    del v2
     again = bs.decode()
     assert torch.equal(fine, again)
     del again

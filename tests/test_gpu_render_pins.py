@@ -341,6 +341,10 @@ def test_skip_grid_strip_kernel_equals_definition(vr, monkeypatch, dims):
                 blk = vol[cz * 8:cz * 8 + 9, cy * 8:cy * 8 + 9, cx * 8:cx * 8 + 9]
                 want[cz, cy, cx] = (blk.min(), blk.max())
     assert np.array_equal(g, want.reshape(-1, 2))
-    monkeypatch.setenv("VRHIP_SKIP_GRID_V1", "1")
-    g1 = vr.build_skip_grid(dvol, (X, Y, Z), 8).cpu().numpy().reshape(-1, 2)
+    from volumerenderer_amd import _lib
+    assert _lib.lib().vr_debug_set(b"skip_grid_v1", 1) == 0
+    try:
+        g1 = vr.build_skip_grid(dvol, (X, Y, Z), 8).cpu().numpy().reshape(-1, 2)
+    finally:
+        _lib.lib().vr_debug_set(b"skip_grid_v1", 0)
     assert np.array_equal(g1, g)

@@ -82,6 +82,8 @@ SIGNATURES = {
     "vr_composite_slabs": (_I32, [_P, _I32, _I64, _I64, _I32, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
     "vr_brickset_last_timings": (_I32, [_P, C.POINTER(C.c_float)]),
     "vr_brickset_set_concurrency": (_I32, [_P, C.c_int32]),
+    "vr_brickset_set_switch": (_I32, [_P, C.c_char_p, C.c_int32]),
+    "vr_debug_set": (_I32, [C.c_char_p, C.c_int32]),
 }
 
 _lib = None

@@ -64,6 +64,10 @@ class BrickSet:
     def set_max_epochs(self, e):
         check(self._L.vr_brickset_set_max_epochs(self._h, int(e)), "setMaxEpochs")
 
+    def set_switch(self, name, value=1):
+        """Debugging switch of this set (vr_brickset_set_switch): which kernel serves the next calls."""
+        check(self._L.vr_brickset_set_switch(self._h, name.encode(), int(value)), "vr_brickset_set_switch(%s)" % name)
+
     def build(self, voxels, stream=None):
         v = _as_dev_u8(voxels)
         if v.numel() != self.num_bricks * self.voxels_per_brick:

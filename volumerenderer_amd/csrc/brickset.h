@@ -16,8 +16,24 @@ struct Stream2 {              // one 2-bit stream (mid, or MidRangeTree's half-r
     uint8_t *treeCompact = nullptr; // B * treeCap  fused builds: the contiguous stream, made on demand (compact_launch)
 };
 
+// Debugging / experiment switches.  Read from the environment (VRHIP_<NAME>) ONCE, when a set is created, or set
+// explicitly with vr_brickset_set_switch -- never in a launch path: the kernels a handle uses do not change behind
+// the caller's back, and buffers sized under one setting are not used under another.
+struct Switches {
+    bool decodeV1 = false;       // VRHIP_DECODE_V1: k_decode_lane for everything
+    bool decodeWalk = false;     // VRHIP_DECODE_WALK: k_decode_tile (no per-4-leaf counts)
+    bool decodeFineV1 = false;   // VRHIP_DECODE_FINE_V1: round 1's k_decode_fine
+    bool decodeQuad = false;     // VRHIP_DECODE_QUAD: round 2's k_decode_quad instead of k_decode_region
+    bool noFusedEmit = false;    // VRHIP_NO_FUSED_EMIT
+    bool noSkipBlocks = false;   // VRHIP_NO_SKIP_BLOCKS
+    bool noSwz = false;          // VRHIP_NOSWZ
+    bool mrSerial = false;       // VRHIP_MR_SERIAL
+    int forkBricks = 0;          // VRHIP_FORK_BRICKS (0: default)
+};
+
 struct BrickSet {
     int32_t B = 0;
+    Switches sw;
     Geom g{};
     int32_t D = 0, maxDepth = 0;
     int32_t tolerance = 6, maxEpochs = 5, variant = 0;
@@ -52,9 +68,8 @@ struct BrickSet {
     std::vector<uint8_t> fineHas; // per brick: fineIdx describes its current stream (all set -> k_decode_fine)
     uint32_t *decTables = nullptr; // B * FD_TABLE_WORDS: k_decode_fine's tables of every brick for the current cut
     uint8_t *idxVal3 = nullptr;   // B * nIdx * 8   decoded scalar of every depth-(D-3) node (k_decode_quad; with fineIdx)
-    uint32_t *chainTab = nullptr; // 16384 entries: k_decode_quad's grown-branch table for `chainTabLevels` refining levels
-    int chainTabLevels = -1;
-    void *chainTabStream = nullptr;
+    uint32_t *chainTab = nullptr; // 8 x 16384 entries: k_decode_quad's grown-branch tables, one per number of refining levels (0..7),
+    bool chainTabReady = false;   // all written once (never rewritten: decodes of one set on several streams may share them)
     std::vector<std::vector<uint8_t>> hostTree; // foreign streams keep their bytes for progressive cuts
     uint32_t *lut = nullptr;    // 2^K : local rank -> packed (dx | dy<<10 | dz<<20)
     bool foreignRange = false;   // a foreign MidRangeTree file also supplied the range stream

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
@@ -22,6 +23,7 @@ int composite_slabs_launch(const float *, int, int64_t, int64_t, int, const vr_c
 int assemble_launch(bool, const uint8_t *, uint8_t *, int, const int64_t bd[3], const int64_t *, const int64_t grid[3], hipStream_t);
 int measure_error_launch(const uint8_t *, const uint8_t *, int64_t, int *, unsigned long long *, hipStream_t);
 int query_error_launch(const uint8_t *, const uint8_t *, int64_t, uint8_t *, hipStream_t);
+extern std::atomic<int> g_skipGridV1;
 }
 
 struct vr_brickset { BrickSet s; };
@@ -178,7 +180,7 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
     HIPCHK(hipMalloc(&b.blockOff, B * (size_t)b.nEmitBlk * sizeof(uint32_t)));
     if (b.idx64) {
         HIPCHK(hipMalloc(&b.blockOff64, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
-        HIPCHK(hipMalloc(&b.idxBase, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));
+        if (!b.idxBase) HIPCHK(hipMalloc(&b.idxBase, B * (size_t)b.nEmitBlk * sizeof(unsigned long long)));    // (set_tree may have made it)
     }
     return VR_OK;
 }
@@ -219,8 +221,8 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     if (tolerance < 0 || max_epochs < 0 || variant < 0 || variant > 2) return VR_ERR_INVALID;
     for (int k = 0; k < 3; ++k) if (dims[k] <= 0) return VR_ERR_INVALID;
     // power-of-two extents up to 1024 per axis take the tiled kernels; anything else (the reference accepts any
-    // extents, R.cpp:26-36,151-162) goes through the general-extent tables.  One tree holds at most 2^28 leaves and
-    // 2^31 voxels here (32-bit ranks, voxel indices and token offsets).
+    // extents, R.cpp:26-36,151-162) goes through the general-extent tables.  Limits: origTreeDepth <= 31, fewer than
+    // 2^32 voxels per tree, and above depth 28 (64-bit token offsets) one tree per set.
     bool general = !pow2(dims[0]) || !pow2(dims[1]) || !pow2(dims[2]) || dims[0] > 1024 || dims[1] > 1024 || dims[2] > 1024;
     if (dims[0] > (1ll << 20) || dims[1] > (1ll << 20) || dims[2] > (1ll << 20) || dims[0] * dims[1] * dims[2] >= (1ll << 32))
         return VR_ERR_UNSUPPORTED;
@@ -229,12 +231,24 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     if (!h) return VR_ERR_OOM;
     BrickSet &b = h->s;
     b.B = num_bricks;
+    {   // the VRHIP_* debugging switches are read here, once per set (brickset.h Switches)
+        Switches &w = b.sw;
+        w.decodeV1 = getenv("VRHIP_DECODE_V1") != nullptr;
+        w.decodeWalk = getenv("VRHIP_DECODE_WALK") != nullptr;
+        w.decodeFineV1 = getenv("VRHIP_DECODE_FINE_V1") != nullptr;
+        w.decodeQuad = getenv("VRHIP_DECODE_QUAD") != nullptr;
+        w.noFusedEmit = getenv("VRHIP_NO_FUSED_EMIT") != nullptr;
+        w.noSkipBlocks = getenv("VRHIP_NO_SKIP_BLOCKS") != nullptr;
+        w.noSwz = getenv("VRHIP_NOSWZ") != nullptr;
+        w.mrSerial = getenv("VRHIP_MR_SERIAL") != nullptr;
+        if (const char *e = getenv("VRHIP_FORK_BRICKS")) { const long v = strtol(e, nullptr, 10); w.forkBricks = v >= 1 && v <= 4 ? (int)v : 0; }
+    }
     make_geom(b.g, dims);
     b.D = b.g.D;
     if (b.D > 31) { delete h; return VR_ERR_UNSUPPORTED; }
     // deeper than 28 (the reference's own 2048x2048x768 tree is 31 deep, main.cpp:242-251): a stream can pass 2^32
     // tokens, so the emitter scans in 64 bits and the decode index goes block-relative; table-driven geometry only
-    b.idx64 = b.D > 28 || (getenv("VRHIP_FORCE_IDX64") && b.D >= 12);
+    b.idx64 = b.D > 28 || (getenv("VRHIP_FORCE_IDX64") && b.D >= 12);      // (create-time only, like the switches above)
     if (b.idx64) general = true;       // the tiled decoders read absolute 32-bit index entries
     if (b.idx64 && num_bricks != 1 && b.D > 28) { delete h; return VR_ERR_UNSUPPORTED; }
     b.generalGeom = general;
@@ -293,6 +307,34 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     b.openTreeBytes.assign(b.B, -1);
     *out = h;
     return VR_OK;
+}
+
+vr_status vr_brickset_set_switch(vr_brickset *h, const char *name, int32_t value)
+{
+    if (!h || !name) return VR_ERR_INVALID;
+    Switches &w = h->s.sw;
+    const bool on = value != 0;
+    if (!strcmp(name, "decode_v1")) w.decodeV1 = on;
+    else if (!strcmp(name, "decode_walk")) w.decodeWalk = on;
+    else if (!strcmp(name, "decode_fine_v1")) w.decodeFineV1 = on;
+    else if (!strcmp(name, "decode_quad")) w.decodeQuad = on;
+    else if (!strcmp(name, "no_skip_blocks")) w.noSkipBlocks = on;
+    else if (!strcmp(name, "noswz")) w.noSwz = on;
+    else if (!strcmp(name, "mr_serial")) w.mrSerial = on;
+    else if (!strcmp(name, "fork_bricks")) { if (value < 0 || value > 4) return VR_ERR_INVALID; w.forkBricks = value; }
+    else if (!strcmp(name, "no_fused_emit")) {
+        // the emitter decides the layout of the stream buffer and which side-cars exist: only before the first build
+        if (h->s.built) return VR_ERR_STATE;
+        w.noFusedEmit = on;
+    } else return VR_ERR_INVALID;
+    return VR_OK;
+}
+
+vr_status vr_debug_set(const char *name, int32_t value)
+{
+    if (!name) return VR_ERR_INVALID;
+    if (!strcmp(name, "skip_grid_v1")) { vr::g_skipGridV1.store(value ? 1 : 0); return VR_OK; }
+    return VR_ERR_INVALID;
 }
 
 vr_status vr_brickset_set_error_tolerance(vr_brickset *h, int32_t tol)
@@ -758,11 +800,14 @@ static vr_status assemble_common(bool toVolume, const uint8_t *src, int32_t nb, 
         for (int k = 0; k < 3; ++k)
             if (ijk[3 * b + k] < 0 || ijk[3 * b + k] >= grid[k]) return VR_ERR_INVALID;
     if (!device_ok()) return VR_ERR_NO_DEVICE;
-    // the brick map lives on the device: uploaded once per distinct map and kept (a streaming loop calls this every
-    // frame with the same map; allocating, copying and synchronising each time would serialise the pipeline)
+    // the brick map lives on the device: uploaded once per distinct map and kept for the life of the process (a
+    // streaming loop calls this every frame with the same map; allocating, copying and synchronising each time would
+    // serialise the pipeline).  Cached maps are never freed, so a launch needs no lock; past 64 distinct maps a call
+    // uploads its own copy and releases it after its launch has run.
     static std::mutex mu;
     static std::map<std::vector<int64_t>, int64_t *> cache;
     int64_t *d = nullptr;
+    bool mine = false;
     {
         std::lock_guard<std::mutex> lk(mu);
         std::vector<int64_t> key(ijk, ijk + (size_t)nb * 3);
@@ -771,13 +816,15 @@ static vr_status assemble_common(bool toVolume, const uint8_t *src, int32_t nb, 
         key.push_back(dev);
         auto it = cache.find(key);
         if (it == cache.end()) {
-            if (cache.size() >= 64) { for (auto &kv : cache) hipFree(kv.second); cache.clear(); }
             HIPCHK(hipMalloc(&d, (size_t)nb * 3 * sizeof(int64_t)));
             if (hipMemcpy(d, ijk, (size_t)nb * 3 * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return VR_ERR_NO_DEVICE; }
-            cache.emplace(std::move(key), d);
+            if (cache.size() < 64) cache.emplace(std::move(key), d);
+            else mine = true;
         } else d = it->second;
     }
-    return assemble_launch(toVolume, src, dst, nb, bd, d, grid, (hipStream_t)stream) == 0 ? VR_OK : VR_ERR_NO_DEVICE;
+    const int rc = assemble_launch(toVolume, src, dst, nb, bd, d, grid, (hipStream_t)stream);
+    if (mine) { hipStreamSynchronize((hipStream_t)stream); hipFree(d); }
+    return rc == 0 ? VR_OK : VR_ERR_NO_DEVICE;
 }
 
 vr_status vr_assemble_bricks(const uint8_t *bricks, int32_t nb, const int64_t bd[3], const int64_t *ijk,

@@ -1166,6 +1166,330 @@ k_decode_quad(TileArgs a)
     }
 }
 
+// ---- region decode (the roofline kernel since round 3) ---------------------------------------------------------
+// k_decode_quad's arithmetic on a different decomposition of the volume.  There a wave owned a 128 x 8 x 4 voxel tile
+// (whole output lines) whose tokens lie in EIGHT 4096-leaf block strings, each shared with seven other tiles: every
+// step's stream words were a gather of 16-byte requests from four strings, the side-cars were strided, and the
+// 64 KiB branch table allowed one 16-wave workgroup per CU.  Here
+//   * a WAVE owns one emit block (a depth-(D-12) subtree = 16 x 16 x 16 voxels): ONE contiguous string (read exactly
+//     once by the launch, by this wave) and contiguous side-cars (256 B offsets, 64 B scalars, 1 KiB counts, 512 B
+//     depth-(D-3) scalars);
+//   * the string is streamed into a small per-wave LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces, a few
+//     pieces ahead, refilled as steps retire): a step's four stream words are LDS reads, no register is spent on
+//     request slots and no step waits for a memory round trip;
+//   * a WORKGROUP of eight waves owns the eight emit blocks of a 128 x 16 x 16 region: results go to a shared LDS
+//     image and leave, after one barrier, as whole 128-byte lines (eight lines per store instruction);
+//   * the grown branch is two lookups (tokens 1-4: 256 entries, 5-7: 64 entries, 1.25 KiB instead of 64 KiB) whose
+//     clamp-adds are applied to both leaves of a sibling pair at once in packed 16-bit lanes.
+// LDS per workgroup: 1.4 KiB tables + 32.1 KiB image + 8 rings => two or three workgroups per CU.
+// Word address of quad q (= leaf rank >> 2, 10 bits) inside its block's image: bits 0-5 = the low six bits of q
+// permuted so that the two lowest x bits come first (a 16-byte read then holds four x-neighbours), bits 6-9 = the
+// step q >> 6, and bits 2-4 XORed with the step's low three bits, so that the step accesses (64 consecutive words),
+// the park stores (one 64-leaf block per lane) and the gather's 16-byte reads (with the block images 4 words apart in
+// the banks) are all conflict-free or two-way.
+#ifndef RG_NP
+#define RG_NP 4             // ring pieces of 1 KiB per wave
+#endif
+#ifndef RG_MINW
+#define RG_MINW 4           // waves per SIMD asked of the register allocator (4: two workgroups per CU, 6: three)
+#endif
+#define RG_WAVES 8
+#define RG_BLK_WORDS 1028
+#define RG_RING_MASK (RG_NP * 256 - 1)
+
+struct RegionArgs {
+    const uint8_t *tree;
+    int64_t treeCap;
+    const uint32_t *idxOff;
+    const uint8_t *idxVal;
+    const uint8_t *fine;
+    const uint8_t *val3;
+    int64_t nIdx;
+    const Ctrl *ctrls;
+    uint8_t *out;
+    const uint32_t *spread;
+    int X, Y;
+    int64_t voxels;
+    int D, cut;
+    int lrx, lry;               // log2 of the regions along x and y
+    int jx;                     // position of x among the three deepest split levels (0 = deepest)
+    uint32_t lanePos;           // 6 nibbles: lane bit i handles bit lanePos[i] of (quad & 63)
+    uint32_t parkP[4];          // 16 bytes: image word (0..63) of quad g of a 64-leaf block ...
+    uint32_t parkS;             // 4 bytes:  ... plus that of the block's two low rank bits
+    uint32_t gAddr[4];          // 8 halfwords: image-word contribution of gather bit i (a y or z bit of the 16 x 16 plane)
+    uint32_t gByte;             // 8 nibbles:  byte-in-word contribution of gather bit i
+    uint32_t gOut[8];           // output byte offset contribution of gather bit i
+    uint32_t xRead[2];          // 4 halfwords: image-word XOR of the gather's read k (the x bits above the two lowest)
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan_max_dpp(uint32_t v)
+{
+    v = max(v, dpp_u32<0x111, 0xf>(0, v));
+    v = max(v, dpp_u32<0x112, 0xf>(0, v));
+    v = max(v, dpp_u32<0x114, 0xf>(0, v));
+    v = max(v, dpp_u32<0x118, 0xf>(0, v));
+    v = max(v, dpp_u32<0x142, 0xa>(0, v));
+    v = max(v, dpp_u32<0x143, 0xc>(0, v));
+    return v;
+}
+
+struct RegionShared {
+    uint32_t chainA[256];           // LDS address 0: branch tokens 1-4 -> LO | A << 8 | HI << 16
+    uint32_t chainB[64];            // branch tokens 5-7
+    int d4[4], d5[4];               // 0 / +d / -d / 0 per token at depths D-2, D-1
+    uint32_t d6p[16];               // the same for the two leaf codes of a pair, packed 16-bit lanes, keyed c1 | c2 << 2
+    uint32_t buf[RG_WAVES * RG_BLK_WORDS];
+    uint32_t ring[RG_WAVES][RG_NP * 256];
+};
+
+// a depth-(D-1) node and its two leaves.  y = the 32 bits that start at the node's token, yh the 32 after them;
+// dead3 = 3 where an ancestor is pruned.  Returns the two voxels (bytes 0, 1); used = bits the pair takes.
+__device__ __forceinline__ uint32_t rg_pair(uint32_t y, uint32_t yh, uint32_t dead3, int Vp, const RegionShared &sm, uint32_t &used)
+{
+    const uint32_t c5 = (y & 3u) | dead3;
+    const int V5 = med3i(Vp + *(const int *)((const char *)sm.d5 + (c5 << 2)), 0, 255);
+    const bool pr = c5 == 3u;                               // pruned (or under a pruned node): both voxels = Vp
+    // where the two leaves end: a leaf = its code + the branch up to and including the first '3', at most 8 tokens
+    const uint32_t yl1 = y >> 2;
+    const uint32_t f1 = ffbl_u32(yl1 & (yl1 >> 1) & 0x5555u);
+    const uint32_t e1 = min(f1, 14u);
+    const uint32_t ym1 = ones_from(f1, yl1);                // the tokens from the first '3' on read as '3'
+    const uint32_t yl2 = __builtin_amdgcn_alignbit(yh, y, e1 + 4u);
+    const uint32_t f2 = ffbl_u32(yl2 & (yl2 >> 1) & 0x5555u);
+    const uint32_t e2 = min(f2, 14u);
+    const uint32_t ym2 = ones_from(f2, yl2);
+    // both leaves in packed 16-bit lanes: V5 + code step, then the two composed clamp-adds of the branch.  A leaf's
+    // own clamp to [0, 255] is absorbed by the first table's (f monotone, f(0) = LO, f(255) = HI: k_decode_quad)
+    const uint32_t dl = *(const uint32_t *)((const char *)sm.d6p + (((ym1 & 3u) | ((ym2 & 3u) << 2)) << 2));
+    const uint32_t a1 = *(const uint32_t *)((const char *)sm.chainA + (ym1 & 0x3FCu));
+    const uint32_t a2 = *(const uint32_t *)((const char *)sm.chainA + (ym2 & 0x3FCu));
+    const uint32_t b1 = *(const uint32_t *)((const char *)sm.chainB + ((ym1 >> 8) & 0xFCu));
+    const uint32_t b2 = *(const uint32_t *)((const char *)sm.chainB + ((ym2 >> 8) & 0xFCu));
+    vr_s16x2 v = pk_s((uint32_t)V5 * 0x10001u) + pk_s(dl);
+    v = v + pk_s(__builtin_amdgcn_perm(a2, a1, 0x0A050801u));                               // A: byte 1, sign-extended
+    v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(a2, a1, 0x0C040C00u)));     // LO: byte 0
+    v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(a2, a1, 0x0C060C02u)));     // HI: byte 2
+    v = v + pk_s(__builtin_amdgcn_perm(b2, b1, 0x0A050801u));
+    v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C040C00u)));
+    v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C060C02u)));
+    const uint32_t r = __builtin_amdgcn_perm(0, pk_u(v), 0x0C0C0200u);
+    used = pr ? 2u : e1 + e2 + 6u;
+    return pr ? (uint32_t)Vp * 0x0101u : r;
+}
+
+__global__ void __launch_bounds__(64 * RG_WAVES, RG_MINW)
+k_decode_region(RegionArgs a)
+{
+    __shared__ __attribute__((aligned(16))) RegionShared sm;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int brick = blockIdx.y;
+    const int rid = blockIdx.x;
+    const int rx = rid & ((1 << a.lrx) - 1), ry = (rid >> a.lrx) & ((1 << a.lry) - 1), rz = rid >> (a.lrx + a.lry);
+    // ---- my emit block: the wave-th of the region along x
+    const uint32_t blk = (a.spread[rx * 128 + wave * 16] | a.spread[a.X + ry * 16] | a.spread[a.X + a.Y + rz * 16]) >> 12;
+    const int64_t io = (int64_t)brick * a.nIdx + ((int64_t)blk << 6) + lane;       // lane <-> 64-leaf block `lane` of it
+    const uint32_t off = a.idxOff[io];
+    const uint32_t val0 = a.idxVal[io];
+    // ---- tables (512 threads; the distances arrive with the index entries)
+    {
+        const uint8_t *dmap = a.ctrls[brick].distanceMap;
+        const int t = threadIdx.x;
+        if (t < 320) {
+            const int first = t < 256 ? 0 : 4, n = t < 256 ? 4 : 3, idx = t < 256 ? t : t - 256;
+            int dist[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int depth = a.D + 1 + first + q; dist[q] = (q < n && depth <= a.cut) ? dmap[depth] : 0; }
+            int A = 0, LO = 0, HI = 255;
+            bool go = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tok = (idx >> (2 * q)) & 3;
+                go = go && q < n && tok != 3;
+                const int dl = !go ? 0 : (tok == 1 ? dist[q] : (tok == 2 ? -dist[q] : 0));
+                A += dl;
+                LO = min(max(LO + dl, 0), 255);
+                HI = min(max(HI + dl, 0), 255);
+            }
+            const uint32_t ent = (uint32_t)LO | ((uint32_t)(A & 255) << 8) | ((uint32_t)HI << 16);
+            if (t < 256) sm.chainA[idx] = ent; else sm.chainB[idx] = ent;
+        } else if (t < 328) {
+            const int lv = (t - 320) >> 2, tok = t & 3, depth = a.D - 2 + lv;
+            const int dist = depth <= a.cut ? dmap[depth] : 0;
+            (lv ? sm.d5 : sm.d4)[tok] = tok == 1 ? dist : (tok == 2 ? -dist : 0);
+        } else if (t < 344) {
+            const int k = t - 328, c1 = k & 3, c2 = k >> 2;
+            const int dist = a.D <= a.cut ? dmap[a.D] : 0;
+            const int s1 = c1 == 1 ? dist : (c1 == 2 ? -dist : 0), s2 = c2 == 1 ? dist : (c2 == 2 ? -dist : 0);
+            sm.d6p[k] = ((uint32_t)s1 & 0xFFFFu) | ((uint32_t)s2 << 16);
+        }
+    }
+    const bool liveL = off != VR_IDX_DEAD;
+    const unsigned long long liveMask = __ballot(liveL);
+    uint32_t *buf = sm.buf + wave * RG_BLK_WORDS;
+    const uint32_t laneTerm = (uint32_t)(64 * (lane >> 2)) + (((a.parkS >> (8 * (lane & 3))) & 255u) ^ ((uint32_t)((lane >> 2) & 7) << 2));
+    const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
+    const uint32_t capWords = (uint32_t)(a.treeCap >> 2);
+    uint32_t *ringW = sm.ring[wave];
+    uint32_t wbase = 0, totalPieces = 0, issued = 0, mEnd = 0;
+    const auto issue = [&](uint32_t p) {      // piece p of my string: words [wbase + 256 p, + 256) -> ring slot p mod RG_NP
+        const uint32_t w = wbase + 256u * p + 4u * (uint32_t)lane;
+        if (w + 4u <= capWords)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(W + w),
+                                             (__attribute__((address_space(3))) void *)(ringW + (p & (RG_NP - 1)) * 256), 16, 0, 0);
+    };
+    if (liveMask == 0ull) {
+        // an emit block under pruned nodes: one value per 64-leaf block, no stream, no further side-car
+        const uint32_t rep = val0 * 0x01010101u;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) buf[laneTerm ^ ((a.parkP[gg >> 2] >> (8 * (gg & 3))) & 255u)] = rep;
+    } else {
+        // ---- the string: from the first live 64-leaf block's root to (a bound on) the last one's end.  Known from the
+        // offsets alone, so the DMA starts beside the loads of the counts and depth-(D-3) scalars, not behind them
+        const int firstL = __ffsll((long long)liveMask) - 1, lastL = 63 - __clzll((long long)liveMask);
+        const uint32_t firstOff = (uint32_t)__builtin_amdgcn_readlane((int)off, firstL), lastOff = (uint32_t)__builtin_amdgcn_readlane((int)off, lastL);
+        wbase = (firstOff >> 4) & ~3u;                                  // first word, 16-byte aligned
+        totalPieces = ((((lastOff + 575u + 15u) >> 4) - wbase) + 255u) >> 8;  // (a 64-leaf subtree is at most 63 + 64 * 8 tokens)
+        totalPieces = min(totalPieces, (capWords - wbase + 255u) >> 8);       // (every piece has a lane inside the buffer)
+        uint4 cv = make_uint4(0, 0, 0, 0);
+        uint2 sv = make_uint2(0, 0);
+        if (liveL) {
+            cv = *(const uint4 *)(a.fine + io * 16);
+            sv = *(const uint2 *)(a.val3 + io * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < RG_NP; ++p)
+            if ((uint32_t)p < totalPieces) { issue((uint32_t)p); ++issued; }
+        // ---- park, for each 4-leaf subtree of my 64-leaf block: the scalar of its depth-(D-3) parent (bits 0-7), the
+        // token position of its run relative to the ring's first word (8-23: prefix sum of the side-car counts) and
+        // whether its root exists (24: it owns more tokens than the ancestors heading its run -- a pruned ancestor ends
+        // the run).  A 64-leaf block under a pruned node parks its scalar with "no root" (or its final words, below).
+        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, sw[2] = {sv.x, sv.y};
+        // (a dead block whose whole step of four blocks is dead parks its final words: that step is skipped)
+        const bool stepDead = ((uint32_t)(liveMask >> (lane & 60)) & 15u) == 0u;
+        const uint32_t deadW = stepDead ? val0 * 0x01010101u : val0;
+        uint32_t run = liveL ? off - wbase * 16u : 0u;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) {
+            const uint32_t cgg = (cw[gg >> 2] >> (8 * (gg & 3))) & 255u;
+            const int own = gg == 0 ? 4 : (gg & 1 ? 0 : (gg & 2 ? 1 : (gg & 4 ? 2 : 3)));
+            const uint32_t vgg = (sw[gg >> 3] >> (8 * ((gg >> 1) & 3))) & 255u;
+            const uint32_t w = vgg | (run << 8) | ((uint32_t)(own - (int)cgg) & 0x01000000u);
+            buf[laneTerm ^ ((a.parkP[gg >> 2] >> (8 * (gg & 3))) & 255u)] = liveL ? w : deadW;
+            run += cgg;
+        }
+        mEnd = wave_incl_scan_max_dpp(liveL ? run : 0u);       // end of the last live block up to mine
+    }
+    __syncthreads();        // the tables
+    if (liveMask != 0ull) {
+        // ---- my role in a step: lane l <-> image word l of the step's 64
+        uint32_t qlow = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) qlow |= (((uint32_t)lane >> i) & 1u) << ((a.lanePos >> (4 * i)) & 15u);
+        const uint32_t g = qlow & 15u;
+        const uint32_t ownN = g == 0u ? 4u : (uint32_t)(__ffs((int)g) - 1);     // ancestors (depth >= D-6) whose tokens head my run
+        const uint32_t p0 = 2u * ownN, p1 = p0 + 2u;                           // bit of my root's token / of my first pair's
+#pragma unroll 1
+        for (int s = 0; s < 16; ++s) {
+            if ((((uint32_t)(liveMask >> (4 * s))) & 15u) == 0u) continue;       // (dead blocks parked their final words)
+            const uint32_t endTok = (uint32_t)__builtin_amdgcn_readlane((int)mEnd, 4 * s + 3);
+            // the pieces this step reads must have landed: DMAs retire in issue order
+            {
+                const int need = (int)((((endTok + 15u) >> 4) + 255u) >> 8);
+                const int allow = (int)issued - need;
+                if (allow <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (allow == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#if RG_NP > 2
+                else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
+#if RG_NP > 4
+                else if (allow == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (allow == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (allow == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (allow == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+#endif
+            }
+            const uint32_t addr = (uint32_t)(64 * s) + ((uint32_t)lane ^ ((uint32_t)(s & 7) << 2));
+            const uint32_t pw = buf[addr];
+            const uint32_t rel = (pw >> 8) & 0xFFFFu, wi = rel >> 4, b = (rel & 15u) * 2u;
+            const uint32_t w0 = ringW[wi & RG_RING_MASK], w1 = ringW[(wi + 1u) & RG_RING_MASK],
+                           w2 = ringW[(wi + 2u) & RG_RING_MASK], w3 = ringW[(wi + 3u) & RG_RING_MASK];
+            const int V3 = (int)(pw & 255u);
+            const bool live = (pw & 0x01000000u) != 0u;
+            // my tokens: bits [0, 96) from my first token on
+            const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
+                           hh = __builtin_amdgcn_alignbit(w3, w2, b);
+            const uint32_t c4 = live ? __builtin_amdgcn_ubfe(lo, p0, 2) : 3u;      // my depth-(D-2) root (behind the ancestors' tokens)
+            const int V4 = med3i(V3 + *(const int *)((const char *)sm.d4 + (c4 << 2)), 0, 255);
+            const uint32_t dead3 = c4 == 3u ? 3u : 0u;
+            uint32_t used1, used2;
+            const uint32_t b01 = rg_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead3, V4, sm, used1);
+            const uint32_t p2 = p1 + used1;                   // <= 10 + 34
+            const bool q = p2 >= 32u;
+            const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
+            const uint32_t b23 = rg_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead3, V4, sm, used2);
+            buf[addr] = b01 | (b23 << 16);
+            // refill: the slot of piece p is free once every word of piece p - RG_NP lies before the next step's first
+            // (a step takes fewer than 256 words, so one refill per step keeps up; two leave slack)
+            const uint32_t consumedWord = endTok >> 4;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (issued >= RG_NP && issued < totalPieces && 256u * (issued - (RG_NP - 1)) <= consumedWord) { issue(issued); ++issued; }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no LDS-DMA may outlive the workgroup's LDS)
+    __syncthreads();
+    // ---- gather: a 16-byte row piece of emit block c = lane & 7 per lane, eight whole 128-byte lines per store
+    {
+        const int c = lane & 7;
+        const uint32_t *img = sm.buf + c * RG_BLK_WORDS;
+        uint8_t *O = a.out + (int64_t)brick * a.voxels + ((int64_t)rz * 16 * a.Y + (int64_t)ry * 16) * a.X + (int64_t)rx * 128 + c * 16;
+        // gather bits 0-2 <- lane >> 3, 3-4 <- the store's index, 5-7 <- wave
+        uint32_t addrL = 0, byteL = 0, outL = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool on = ((lane >> (3 + i)) & 1) != 0;
+            addrL ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
+            byteL |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
+            outL += on ? a.gOut[i] : 0u;
+        }
+#pragma unroll
+        for (int i = 5; i < 8; ++i) {
+            const bool on = ((wave >> (i - 5)) & 1) != 0;
+            addrL ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
+            byteL |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
+            outL += on ? a.gOut[i] : 0u;
+        }
+        const uint32_t xr1 = a.xRead[0] >> 16, xr2 = a.xRead[1] & 0xFFFFu, xr3 = a.xRead[1] >> 16;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            uint32_t addr = addrL, bsel = byteL, oo = outL;
+#pragma unroll
+            for (int i = 3; i < 5; ++i) {
+                const bool on = ((it >> (i - 3)) & 1) != 0;
+                addr ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
+                bsel |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
+                oo += on ? a.gOut[i] : 0u;
+            }
+            if (a.jx < 2) {          // x bit 0 lives in the byte index: a word holds two x-neighbours
+                const uint32_t b0 = bsel, b1 = bsel | (1u << a.jx);
+                const uint32_t sel = b0 | (b1 << 8) | ((4u + b0) << 16) | ((4u + b1) << 24);
+                const uint4 P = *(const uint4 *)(img + addr), Q = *(const uint4 *)(img + (addr ^ xr1));
+                store_out16(O + oo, make_uint4(__builtin_amdgcn_perm(P.y, P.x, sel), __builtin_amdgcn_perm(P.w, P.z, sel),
+                                               __builtin_amdgcn_perm(Q.y, Q.x, sel), __builtin_amdgcn_perm(Q.w, Q.z, sel)));
+            } else {                 // jx == 2: four x-neighbours in four words
+                const uint32_t sel = bsel | ((4u + bsel) << 8) | 0x0c0c0000u;
+                const uint4 P = *(const uint4 *)(img + addr), Q = *(const uint4 *)(img + (addr ^ xr1)),
+                            R = *(const uint4 *)(img + (addr ^ xr2)), T = *(const uint4 *)(img + (addr ^ xr3));
+                const auto mk = [sel](const uint4 &u) {
+                    return __builtin_amdgcn_perm(__builtin_amdgcn_perm(u.w, u.z, sel), __builtin_amdgcn_perm(u.y, u.x, sel), 0x05040100u);
+                };
+                store_out16(O + oo, make_uint4(mk(P), mk(Q), mk(R), mk(T)));
+            }
+        }
+    }
+}
+
 static bool tile_geometry(const BrickSet *bs, TileArgs &a)
 {
     const Geom &g = bs->g;
@@ -1197,6 +1521,99 @@ static bool tile_geometry(const BrickSet *bs, TileArgs &a)
         }
         for (int b = 0; b < 8; ++b) if (!used[b]) a.kqBit[n++] = (uint8_t)b;
     }
+    return true;
+}
+
+// k_decode_region's geometry: the twelve deepest levels must be four (a, b, c) triples in one axis order, deciding
+// coordinate bits 3, 2, 1, 0 (a 4096-leaf emit block is then a 16 x 16 x 16 box), with whole 128 x 16 x 16 regions
+static bool region_geometry(const BrickSet *bs, RegionArgs &a)
+{
+    const Geom &g = bs->g;
+    const int D = g.D;
+    if (bs->K != 6 || D < 12 || bs->generalGeom || bs->idx64 || (bs->treeCap & 15)) return false;
+    if (g.X < 128 || g.Y < 16 || g.Z < 16) return false;
+    if ((g.X & (g.X - 1)) || (g.Y & (g.Y - 1)) || (g.Z & (g.Z - 1))) return false;
+    int pos[3] = {-1, -1, -1};
+    for (int q = 0; q < 3; ++q) pos[g.axis[D - 3 + q]] = 2 - q;           // deepest level -> rank bit 0
+    if (pos[0] < 0 || pos[1] < 0 || pos[2] < 0) return false;
+    for (int k = 0; k < 4; ++k)
+        for (int q = 0; q < 3; ++q) {
+            const int d = D - 3 * (k + 1) + q;
+            if (g.axis[d] != g.axis[D - 3 + q] || g.bit[d] != k) return false;
+        }
+    const int jx = pos[0], jy = pos[1], jz = pos[2];
+    // quad index q = leaf rank >> 2 (10 bits).  Bits 0-5 go to lane / image-word bits: the two lowest x bits first
+    int Pmap[6], nx = 0, nxt = 2;
+    bool isx[6] = {false, false, false, false, false, false};
+    for (int k = 0; k < 4; ++k) {
+        const int qb = 3 * k + jx - 2;
+        if (qb >= 0 && qb < 6) { isx[qb] = true; Pmap[qb] = nx++; }
+    }
+    if (nx != 2) return false;
+    for (int qb = 0; qb < 6; ++qb) if (!isx[qb]) Pmap[qb] = nxt++;
+    a.lanePos = 0;
+    for (int qb = 0; qb < 6; ++qb) a.lanePos |= (uint32_t)qb << (4 * Pmap[qb]);
+    for (int i = 0; i < 4; ++i) a.parkP[i] = 0;
+    for (int gg = 0; gg < 16; ++gg) {
+        uint32_t w = 0;
+        for (int i = 0; i < 4; ++i) if ((gg >> i) & 1) w |= 1u << Pmap[i];
+        a.parkP[gg >> 2] |= w << (8 * (gg & 3));
+    }
+    a.parkS = 0;
+    for (int sv = 0; sv < 4; ++sv) {
+        uint32_t w = 0;
+        if (sv & 1) w |= 1u << Pmap[4];
+        if (sv & 2) w |= 1u << Pmap[5];
+        a.parkS |= w << (8 * sv);
+    }
+    // image-word contribution of quad-index bit qb (XOR-linear: a permutation plus the step swizzle)
+    const auto contrib = [&](int qb) -> uint32_t {
+        if (qb < 6) return 1u << Pmap[qb];
+        const int i = qb - 6;
+        return (1u << (6 + i)) | (i < 3 ? 1u << (2 + i) : 0u);
+    };
+    // the eight (y, z) bits of a region's 16 x 16 plane
+    struct GB { uint32_t addr, byte, out; } bits[8], ord[8];
+    for (int ax = 1; ax <= 2; ++ax)
+        for (int k = 0; k < 4; ++k) {
+            const int rb = 3 * k + (ax == 1 ? jy : jz);
+            GB &b = bits[(ax - 1) * 4 + k];
+            b.addr = rb < 2 ? 0u : contrib(rb - 2);
+            b.byte = rb < 2 ? 1u << rb : 0u;
+            b.out = ax == 1 ? (uint32_t)((1 << k) * g.X) : (uint32_t)((int64_t)(1 << k) * g.X * g.Y);
+        }
+    // gather bits 0-2 come from lane >> 3: bit 1 the plane bit at image bit 5 (the 16-byte bank slot's top bit), bits 0
+    // and 2 plane bits that do not move the slot at all (byte index, image bit 9): the eight rows of a store instruction
+    // then read conflict-free (the lanes of one row are the eight emit blocks, 4 words = one slot apart)
+    bool used[8] = {false, false, false, false, false, false, false, false};
+    int n = 0;
+    const auto take = [&](int i) { ord[n++] = bits[i]; used[i] = true; };
+    int free0 = -1, free1 = -1, top = -1;
+    for (int i = 0; i < 8; ++i) {
+        if (bits[i].addr == 32u && top < 0) top = i;
+        else if ((bits[i].addr & 0x3Cu) == 0u) { if (free0 < 0) free0 = i; else if (free1 < 0) free1 = i; }
+    }
+    if (free0 >= 0) take(free0); else { for (int i = 0; i < 8; ++i) if (!used[i] && i != top && i != free1) { take(i); break; } }
+    if (top >= 0) take(top); else { for (int i = 0; i < 8; ++i) if (!used[i] && i != free1) { take(i); break; } }
+    if (free1 >= 0) take(free1); else { for (int i = 0; i < 8; ++i) if (!used[i]) { take(i); break; } }
+    for (int i = 0; i < 8; ++i) if (!used[i]) take(i);
+    for (int i = 0; i < 4; ++i) a.gAddr[i] = 0;
+    a.gByte = 0;
+    for (int i = 0; i < 8; ++i) {
+        a.gAddr[i >> 1] |= ord[i].addr << (16 * (i & 1));
+        a.gByte |= ord[i].byte << (4 * i);
+        a.gOut[i] = ord[i].out;
+    }
+    // x bits above the two lowest: the gather's reads
+    uint32_t xr[4] = {0, 0, 0, 0};
+    if (jx < 2) xr[1] = contrib(3 * 3 + jx - 2);
+    else { xr[1] = contrib(6); xr[2] = contrib(9); xr[3] = xr[1] ^ xr[2]; }
+    a.xRead[0] = xr[0] | (xr[1] << 16);
+    a.xRead[1] = xr[2] | (xr[3] << 16);
+    a.jx = jx;
+    a.X = g.X; a.Y = g.Y; a.voxels = g.voxels;
+    a.lrx = 0; while ((128 << a.lrx) < g.X) ++a.lrx;
+    a.lry = 0; while ((16 << a.lry) < g.Y) ++a.lry;
     return true;
 }
 
@@ -1251,7 +1668,7 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         hipLaunchKernelGGL(k_decode_lane<true>, dim3((unsigned)((bs->nIdx + 63) / 64), bs->B), dim3(64), 0, st, a);
         hipLaunchKernelGGL(k_owner_gather, dim3((unsigned)((bs->g.voxels + 255) / 256), bs->B), dim3(256), 0, st,
                            (const uint16_t *)bs->rankVals, bs->leafStride, bs->ownerRank, bs->ownerSurv, bs->g.voxels, out);
-    } else if (!getenv("VRHIP_DECODE_V1") && tile_geometry(bs, t)) {
+    } else if (!bs->sw.decodeV1 && tile_geometry(bs, t)) {
         t.tree = sm.tree; t.treeCap = bs->treeCap;
         t.idxOff = bs->idxOff; t.idxVal = idxVals; t.nIdx = bs->nIdx;
         t.ctrls = sm.ctrl; t.out = out; t.g = bs->g; t.D = bs->D; t.Ds = bs->Ds;
@@ -1259,20 +1676,31 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
         const int ntiles = t.tilesX * t.tilesY * t.tilesZ;
         t.fine = bs->fineIdx;
         t.val3 = bs->idxVal3;
-        bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !rangeStream && !getenv("VRHIP_DECODE_WALK");
+        bool useFine = bs->fineIdx && (int)bs->fineHas.size() == bs->B && !rangeStream && !bs->sw.decodeWalk;
         for (int i = 0; useFine && i < bs->B; ++i) useFine = bs->fineHas[(size_t)i] != 0;
-        // k_decode_quad: cuts at or below depth D-3 (the third side-car holds the depth-(D-3) scalars at full
-        // precision); shallower progressive cuts keep k_decode_fine, which decodes the upper nodes itself
-        const bool useQuad = useFine && bs->idxVal3 && cut >= bs->D - 3 && !getenv("VRHIP_DECODE_FINE_V1");
-        if (useQuad) {
+        // k_decode_region / k_decode_quad: cuts at or below depth D-3 (the third side-car holds the depth-(D-3) scalars
+        // at full precision); shallower progressive cuts keep k_decode_fine, which decodes the upper nodes itself
+        const bool useQuad = useFine && bs->idxVal3 && cut >= bs->D - 3 && !bs->sw.decodeFineV1;
+        RegionArgs r;
+        if (useQuad && !bs->sw.decodeQuad && region_geometry(bs, r)) {
+            r.tree = sm.tree; r.treeCap = bs->treeCap;
+            r.idxOff = bs->idxOff; r.idxVal = idxVals; r.fine = bs->fineIdx; r.val3 = bs->idxVal3; r.nIdx = bs->nIdx;
+            r.ctrls = sm.ctrl; r.out = out; r.spread = bs->spread; r.D = bs->D; r.cut = cut;
+            const unsigned regions = (unsigned)((bs->g.X / 128) * (bs->g.Y / 16) * (bs->g.Z / 16));
+            hipLaunchKernelGGL(k_decode_region, dim3(regions, bs->B), dim3(64 * RG_WAVES), 0, st, r);
+        } else if (useQuad) {
             const int levels = cut - bs->D < 0 ? 0 : (cut - bs->D > VR_CHAIN_LEVELS ? VR_CHAIN_LEVELS : cut - bs->D);
-            if (!bs->chainTab && hipMalloc(&bs->chainTab, (size_t)QD_CHAIN_ENTRIES * 4) != hipSuccess) return -3;
-            if (bs->chainTabLevels != levels || bs->chainTabStream != (void *)st) {   // stream order keeps its readers safe
-                hipLaunchKernelGGL(k_chain_table, dim3(QD_CHAIN_ENTRIES / 256), dim3(256), 0, st, levels, bs->chainTab);
-                bs->chainTabLevels = levels;
-                bs->chainTabStream = (void *)st;
+            // one table per number of refining levels, all written once: two decodes of one set on different streams at
+            // different cuts never rewrite a table the other is reading
+            if (!bs->chainTab && hipMalloc(&bs->chainTab, (size_t)(VR_CHAIN_LEVELS + 1) * QD_CHAIN_ENTRIES * 4) != hipSuccess) return -3;
+            if (!bs->chainTabReady) {
+                for (int lv = 0; lv <= VR_CHAIN_LEVELS; ++lv)
+                    hipLaunchKernelGGL(k_chain_table, dim3(QD_CHAIN_ENTRIES / 256), dim3(256), 0, st, lv, bs->chainTab + (size_t)lv * QD_CHAIN_ENTRIES);
+                // (the first use may come from any stream: make the tables visible to all of them before going on)
+                if (hipStreamSynchronize(st) != hipSuccess) return -1;
+                bs->chainTabReady = true;
             }
-            t.tables = bs->chainTab;
+            t.tables = bs->chainTab + (size_t)levels * QD_CHAIN_ENTRIES;
             const int per = QD_WAVES * QD_TPW;
             hipLaunchKernelGGL(k_decode_quad, dim3((unsigned)((ntiles + per - 1) / per), bs->B), dim3(64 * QD_WAVES), 0, st, t);
         } else {

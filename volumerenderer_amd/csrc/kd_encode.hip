@@ -2620,10 +2620,10 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     const bool mr = bs->variant == 2;
     hipEventRecord(bs->ev[0], st);
     const uint8_t *rootMinP = nullptr, *rootMaxP = nullptr;   // where the last pyramid round leaves each brick's root (min,max)
-    const bool fused = D >= 12 && bs->K == 6 && !getenv("VRHIP_NO_FUSED_EMIT");   // prune + block-local emit in one kernel
+    const bool fused = D >= 12 && bs->K == 6 && !bs->sw.noFusedEmit;   // prune + block-local emit in one kernel
     // SkipBlocks needs k_pyramid12's constant bit in front and k_prune_emit12 behind, a prune that makes such blocks
     // one token (tolerance >= 1) and a level loop that runs
-    bool skipOn = fused && bs->blockFlag && (!mr || bs->blockFlagR) && bs->tolerance >= 1 && bs->maxEpochs >= 1 && D >= 14 && !getenv("VRHIP_NO_SKIP_BLOCKS");
+    bool skipOn = fused && bs->blockFlag && (!mr || bs->blockFlagR) && bs->tolerance >= 1 && bs->maxEpochs >= 1 && D >= 14 && !bs->sw.noSkipBlocks;
     const int64_t rootStride = (int64_t)1 << (D > 10 ? D - 10 : 0);
     // ---- BUILD: pyramid.  Bottom 12 levels by k_pyramid12 when x-runs of 16 voxels exist,
     // the rest (and small / thin bricks) in rounds of <= 10 levels.
@@ -2655,7 +2655,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         if (use12) {
             const int64_t Bx = bs->g.X >> pg.ax, By = bs->g.Y >> pg.ay, Bz = bs->g.Z >> pg.az;
             const int64_t perLine = (bs->g.X < 128 ? bs->g.X : 128) >> pg.ax;
-            pg.swz = (perLine == 8 && Bx % 8 == 0 && ((Bx / 8) * By * Bz) % 8 == 0 && !getenv("VRHIP_NOSWZ")) ? 1 : 0;
+            pg.swz = (perLine == 8 && Bx % 8 == 0 && ((Bx / 8) * By * Bz) % 8 == 0 && !bs->sw.noSwz) ? 1 : 0;
             pg.nbx = (int)Bx; pg.nby = (int)By;
             pg.lnbx = 0; while ((1 << pg.lnbx) < pg.nbx) ++pg.lnbx;
             pg.lnby = 0; while ((1 << pg.lnby) < pg.nby) ++pg.lnby;
@@ -2697,7 +2697,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // MidRangeTree: the two streams' level loops do not depend on each other (M.cpp:399-544 runs them one after the
     // other): the half-range stream's goes to the set's second stream, so its one-wave-per-brick walkers run beside
     // the mid stream's wide kernels and the other way round
-    const bool forkR = mr && bs->blockErrR && bs->estSummR && !getenv("VRHIP_MR_SERIAL") && ensure_aux(bs, 1) == 1;
+    const bool forkR = mr && bs->blockErrR && bs->estSummR && !bs->sw.mrSerial && ensure_aux(bs, 1) == 1;
     if (forkR) {
         hipEventRecord(bs->evFork, st);
         hipStreamWaitEvent(bs->aux, bs->evFork, 0);
@@ -2707,7 +2707,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     }
     // VolumeKdtree: the same trick over ranges of the bricks (vr_brickset_set_concurrency; 2 by default)
     int parts = bs->levelLoopStreams;
-    if (const char *e = getenv("VRHIP_FORK_BRICKS")) parts = atoi(e);
+    if (bs->sw.forkBricks > 0) parts = bs->sw.forkBricks;
     if (parts > 4) parts = 4;
     if (mr || B < 16 * parts || parts < 2) parts = 1;
     if (parts > 1) parts = 1 + ensure_aux(bs, parts - 1);

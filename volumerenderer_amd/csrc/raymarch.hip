@@ -13,6 +13,8 @@
 #include "kd_common.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
+#include <atomic>
 
 namespace vr {
 
@@ -444,11 +446,20 @@ int raycast_launch(const uint8_t *vol, const int64_t dims[3], const vr_camera *c
     return launch_status("raymarch");
 }
 
+// process-wide debugging switch (vr_debug_set("skip_grid_v1", 1), or VRHIP_SKIP_GRID_V1 in the environment when the
+// library is first used): the one-wave-per-cell kernel for every grid
+std::atomic<int> g_skipGridV1{-1};
+
 int skip_grid_launch(const uint8_t *vol, const int64_t dims[3], int S, uint8_t *grid, hipStream_t st)
 {
+    int v1 = g_skipGridV1.load(std::memory_order_relaxed);
+    if (v1 < 0) { v1 = getenv("VRHIP_SKIP_GRID_V1") ? 1 : 0; g_skipGridV1.store(v1, std::memory_order_relaxed); }
+    // k_skip_grid8 loads 16 bytes per lane and stores (min, max) pairs as 32-bit words: an offset sub-buffer of a
+    // caller's allocation goes through the byte-wise kernel
     const int nx = (int)((dims[0] + S - 1) / S), ny = (int)((dims[1] + S - 1) / S), nz = (int)((dims[2] + S - 1) / S);
     const int64_t cells = (int64_t)nx * ny * nz;
-    if (S == 8 && (dims[0] & 127) == 0 && !getenv("VRHIP_SKIP_GRID_V1")) {
+    const bool aligned = (((uintptr_t)vol & 15u) == 0u) && (((uintptr_t)grid & 3u) == 0u);
+    if (S == 8 && (dims[0] & 127) == 0 && !v1 && aligned) {
         const int64_t strips = (dims[0] >> 7) * (int64_t)ny * nz;
         hipLaunchKernelGGL(k_skip_grid8, dim3((unsigned)((strips + 3) / 4)), dim3(256), 0, st, vol, (int)dims[0], (int)dims[1],
                            (int)dims[2], nx, ny, nz, grid);
