@@ -8,6 +8,7 @@
 // decoded independently.
 #include "brickset.h"
 #include <stdio.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1193,6 +1194,9 @@ k_decode_quad(TileArgs a)
 #ifndef RG_MINW
 #define RG_MINW 4           // waves per SIMD asked of the register allocator (4: two workgroups per CU, 6: three)
 #endif
+#ifndef RG_PER
+#define RG_PER 32           // regions per workgroup
+#endif
 #define RG_WAVES 8
 #define RG_BLK_WORDS 1028
 #define RG_RING_MASK (RG_NP * 256 - 1)
@@ -1220,6 +1224,9 @@ struct RegionArgs {
     uint32_t gByte;             // 8 nibbles:  byte-in-word contribution of gather bit i
     uint32_t gOut[8];           // output byte offset contribution of gather bit i
     uint32_t xRead[2];          // 4 halfwords: image-word XOR of the gather's read k (the x bits above the two lowest)
+    uint32_t blkX, blkY, blkZ;  // 6 x 5 bits each: bit k of x >> 4 (y >> 4, z >> 4) is this bit of the emit block's number (= leaf rank >> 12)
+    int nreg;                   // regions of a brick
+    unsigned long long *dbg;    // RG_STAMP builds only: cycle sums (total, park, steps, barrier 1, gather, barrier 2)
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan_max_dpp(uint32_t v)
@@ -1233,29 +1240,41 @@ __device__ __forceinline__ uint32_t wave_incl_scan_max_dpp(uint32_t v)
     return v;
 }
 
+// A workgroup barrier that orders LDS only.  __syncthreads() also drains the vector-memory counter while an LDS-DMA
+// is pending (its fence cannot tell the DMA's LDS write from a store): every barrier of the pipelined loop would
+// wait for the next region's loads and string pieces, which exist to be in flight across it.
+__device__ __forceinline__ void rg_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct RegionShared {
     uint32_t chainA[256];           // LDS address 0: branch tokens 1-4 -> LO | A << 8 | HI << 16
     uint32_t chainB[64];            // branch tokens 5-7
     int d4[4], d5[4];               // 0 / +d / -d / 0 per token at depths D-2, D-1
     uint32_t d6p[16];               // the same for the two leaf codes of a pair, packed 16-bit lanes, keyed c1 | c2 << 2
     uint32_t buf[RG_WAVES * RG_BLK_WORDS];
-    uint32_t ring[RG_WAVES][RG_NP * 256];
+    uint32_t ring[RG_WAVES][RG_NP * 256 + 4];      // + 4: the ring's first words again (a lane reads 4 consecutive words)
 };
 
 // a depth-(D-1) node and its two leaves.  y = the 32 bits that start at the node's token, yh the 32 after them;
 // dead3 = 3 where an ancestor is pruned.  Returns the two voxels (bytes 0, 1); used = bits the pair takes.
+// A pruned pair is data, not control: its leaves' tokens are forced to read '3' (code step 0, both branch tables the
+// identity) and its own step is 0, so the table path returns the parent's scalar for both voxels.
 __device__ __forceinline__ uint32_t rg_pair(uint32_t y, uint32_t yh, uint32_t dead3, int Vp, const RegionShared &sm, uint32_t &used)
 {
     const uint32_t c5 = (y & 3u) | dead3;
     const int V5 = med3i(Vp + *(const int *)((const char *)sm.d5 + (c5 << 2)), 0, 255);
     const bool pr = c5 == 3u;                               // pruned (or under a pruned node): both voxels = Vp
-    // where the two leaves end: a leaf = its code + the branch up to and including the first '3', at most 8 tokens
+    const uint32_t keep = pr ? 0u : ~0u;
+    // where the two leaves end: a leaf = its code + the branch up to and including the first '3', at most 8 tokens.
+    // In a pruned pair both "end at once" (f = 0): their tokens all read '3' below.
     const uint32_t yl1 = y >> 2;
-    const uint32_t f1 = ffbl_u32(yl1 & (yl1 >> 1) & 0x5555u);
+    const uint32_t f1 = ffbl_u32(yl1 & (yl1 >> 1) & 0x5555u) & keep;
     const uint32_t e1 = min(f1, 14u);
     const uint32_t ym1 = ones_from(f1, yl1);                // the tokens from the first '3' on read as '3'
     const uint32_t yl2 = __builtin_amdgcn_alignbit(yh, y, e1 + 4u);
-    const uint32_t f2 = ffbl_u32(yl2 & (yl2 >> 1) & 0x5555u);
+    const uint32_t f2 = ffbl_u32(yl2 & (yl2 >> 1) & 0x5555u) & keep;
     const uint32_t e2 = min(f2, 14u);
     const uint32_t ym2 = ones_from(f2, yl2);
     // both leaves in packed 16-bit lanes: V5 + code step, then the two composed clamp-adds of the branch.  A leaf's
@@ -1272,28 +1291,92 @@ __device__ __forceinline__ uint32_t rg_pair(uint32_t y, uint32_t yh, uint32_t de
     v = v + pk_s(__builtin_amdgcn_perm(b2, b1, 0x0A050801u));
     v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C040C00u)));
     v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C060C02u)));
-    const uint32_t r = __builtin_amdgcn_perm(0, pk_u(v), 0x0C0C0200u);
     used = pr ? 2u : e1 + e2 + 6u;
-    return pr ? (uint32_t)Vp * 0x0101u : r;
+    return __builtin_amdgcn_perm(0, pk_u(v), 0x0C0C0200u);
 }
+
+// one step's decode: my four voxels from my park word and the four stream words behind it
+__device__ __forceinline__ uint32_t rg_quad(uint32_t pw, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t p0, uint32_t p1,
+                                            const RegionShared &sm)
+{
+#ifdef RG_KO_COMPUTE        // (timing experiments: the step's arithmetic replaced by an XOR of its inputs)
+    return pw ^ w0 ^ w1 ^ w2 ^ w3 ^ p0;
+#endif
+    const uint32_t b = (pw >> 7) & 30u;                    // bit of my first token in w0
+    const int V3 = (int)(pw & 255u);
+    const uint32_t dead = ((pw >> 24) & 1u) - 1u;           // all ones <=> my root does not exist
+    // my tokens: bits [0, 96) from my first token on
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
+                   hh = __builtin_amdgcn_alignbit(w3, w2, b);
+    const uint32_t c4 = __builtin_amdgcn_ubfe(lo, p0, 2) | (dead & 3u);      // my depth-(D-2) root (behind the ancestors' tokens)
+    const int V4 = med3i(V3 + *(const int *)((const char *)sm.d4 + (c4 << 2)), 0, 255);
+    const uint32_t dead3 = c4 == 3u ? 3u : 0u;
+    uint32_t used1, used2;
+    const uint32_t b01 = rg_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead3, V4, sm, used1);
+    const uint32_t p2 = p1 + used1;                   // <= 10 + 34
+    const bool q = p2 >= 32u;
+    const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
+    const uint32_t b23 = rg_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead3, V4, sm, used2);
+    return b01 | (b23 << 16);
+}
+
+// "all but the n youngest vector-memory operations of this wave are done", n known only at run time
+__device__ __forceinline__ void rg_vm_wait(uint32_t n)
+{
+    switch (n < 24u ? n : 24u) {
+#define RG_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    RG_W(0) RG_W(1) RG_W(2) RG_W(3) RG_W(4) RG_W(5) RG_W(6) RG_W(7) RG_W(8) RG_W(9) RG_W(10) RG_W(11) RG_W(12)
+    RG_W(13) RG_W(14) RG_W(15) RG_W(16) RG_W(17) RG_W(18) RG_W(19) RG_W(20) RG_W(21) RG_W(22) RG_W(23) RG_W(24)
+#undef RG_W
+    }
+}
+
+// LDS-DMA from inline asm: hipcc then neither counts the load nor orders LDS accesses behind it.  (Told about an
+// LDS-DMA -- the builtin -- it waits vmcnt(0) before EVERY later LDS access, because it cannot tell the DMA's LDS
+// destination from the image; and any register load it does know of it waits for with vmcnt(0) inside a loop, which
+// also drains every store and string piece in flight.)  So every load of the pipelined loop is one of these, the
+// data lands in LDS, and the waits are counted by hand: rg_vm_wait(operations issued since).
+#define RG_DMA(SUFFIX, gptr, ldsByte) do { uint32_t keep_; \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_" SUFFIX " %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(gptr), "s"(ldsByte) : "memory"); } while (0)
+
+#ifndef RG_IDXD
+#define RG_IDXD 3           // regions the index entries run ahead
+#endif
 
 __global__ void __launch_bounds__(64 * RG_WAVES, RG_MINW)
 k_decode_region(RegionArgs a)
 {
-    __shared__ __attribute__((aligned(16))) RegionShared sm;
+    // Workgroup i of a brick takes the brick's regions i, i + gridDim.x, ...: tables once, and the regions software-
+    // pipelined.  While region k is decoded and stored, the index entries of regions k+1 .. k+RG_IDXD, and the counts,
+    // depth-(D-3) scalars and first string pieces of region k+1 are in flight or landed, so in steady state no wave
+    // waits for a memory round trip (one workgroup per region spent 2.5 of its 5.4 ms in those round trips alone).
+    struct Shared {
+        RegionShared t;
+        uint32_t idxOff[RG_WAVES][RG_IDXD][64];     // landed index entries: token offset of every 64-leaf block's root ...
+        uint32_t idxVal[RG_WAVES][RG_IDXD][16];     // ... and its scalar (64 bytes)
+        uint32_t blkTab[3][64];                     // emit block number = blkTab[0][x >> 4] | blkTab[1][y >> 4] | blkTab[2][z >> 4]
+    };
+    __shared__ __attribute__((aligned(16))) Shared smw;
+    RegionShared &sm = smw.t;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int brick = blockIdx.y;
-    const int rid = blockIdx.x;
-    const int rx = rid & ((1 << a.lrx) - 1), ry = (rid >> a.lrx) & ((1 << a.lry) - 1), rz = rid >> (a.lrx + a.lry);
-    // ---- my emit block: the wave-th of the region along x
-    const uint32_t blk = (a.spread[rx * 128 + wave * 16] | a.spread[a.X + ry * 16] | a.spread[a.X + a.Y + rz * 16]) >> 12;
-    const int64_t io = (int64_t)brick * a.nIdx + ((int64_t)blk << 6) + lane;       // lane <-> 64-leaf block `lane` of it
-    const uint32_t off = a.idxOff[io];
-    const uint32_t val0 = a.idxVal[io];
-    // ---- tables (512 threads; the distances arrive with the index entries)
+    const int G = (int)gridDim.x;
+    const int nreg = a.nreg;
+    int rid = (int)blockIdx.x;
+    if (rid >= nreg) return;
+    // ---- tables (512 threads)
     {
         const uint8_t *dmap = a.ctrls[brick].distanceMap;
         const int t = threadIdx.x;
+        if (t >= 320 && t < 512) {      // rank bits of the coordinates above the emit block (bit deposit, once per workgroup)
+            const int ax = (t - 320) >> 6, v = (t - 320) & 63;
+            const uint32_t pos = ax == 0 ? a.blkX : (ax == 1 ? a.blkY : a.blkZ);
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r |= (((uint32_t)v >> k) & 1u) << ((pos >> (5 * k)) & 31u);
+            smw.blkTab[ax][v] = r;
+        }
         if (t < 320) {
             const int first = t < 256 ? 0 : 4, n = t < 256 ? 4 : 3, idx = t < 256 ? t : t - 256;
             int dist[4];
@@ -1312,182 +1395,288 @@ k_decode_region(RegionArgs a)
             }
             const uint32_t ent = (uint32_t)LO | ((uint32_t)(A & 255) << 8) | ((uint32_t)HI << 16);
             if (t < 256) sm.chainA[idx] = ent; else sm.chainB[idx] = ent;
-        } else if (t < 328) {
-            const int lv = (t - 320) >> 2, tok = t & 3, depth = a.D - 2 + lv;
+        }
+        if (t < 8) {
+            const int lv = t >> 2, tok = t & 3, depth = a.D - 2 + lv;
             const int dist = depth <= a.cut ? dmap[depth] : 0;
             (lv ? sm.d5 : sm.d4)[tok] = tok == 1 ? dist : (tok == 2 ? -dist : 0);
-        } else if (t < 344) {
-            const int k = t - 328, c1 = k & 3, c2 = k >> 2;
+        } else if (t < 24) {
+            const int k = t - 8, c1 = k & 3, c2 = k >> 2;
             const int dist = a.D <= a.cut ? dmap[a.D] : 0;
             const int s1 = c1 == 1 ? dist : (c1 == 2 ? -dist : 0), s2 = c2 == 1 ? dist : (c2 == 2 ? -dist : 0);
             sm.d6p[k] = ((uint32_t)s1 & 0xFFFFu) | ((uint32_t)s2 << 16);
         }
     }
-    const bool liveL = off != VR_IDX_DEAD;
-    const unsigned long long liveMask = __ballot(liveL);
+    rg_barrier();           // the tables
+    // ---- per-lane constants
     uint32_t *buf = sm.buf + wave * RG_BLK_WORDS;
+    uint32_t *ringW = sm.ring[wave];
+    const auto lds_byte = [](const void *p) { return (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p; };
+    const uint32_t ringLds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte(ringW));
+    const uint32_t idxOffLds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte(smw.idxOff[wave][0]));
+    const uint32_t idxValLds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte(smw.idxVal[wave][0]));
     const uint32_t laneTerm = (uint32_t)(64 * (lane >> 2)) + (((a.parkS >> (8 * (lane & 3))) & 255u) ^ ((uint32_t)((lane >> 2) & 7) << 2));
     const uint32_t *W = (const uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
     const uint32_t capWords = (uint32_t)(a.treeCap >> 2);
-    uint32_t *ringW = sm.ring[wave];
-    uint32_t wbase = 0, totalPieces = 0, issued = 0, mEnd = 0;
-    const auto issue = [&](uint32_t p) {      // piece p of my string: words [wbase + 256 p, + 256) -> ring slot p mod RG_NP
-        const uint32_t w = wbase + 256u * p + 4u * (uint32_t)lane;
-        if (w + 4u <= capWords)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(W + w),
-                                             (__attribute__((address_space(3))) void *)(ringW + (p & (RG_NP - 1)) * 256), 16, 0, 0);
+    // my role in a step: lane l <-> image word l of the step's 64
+    uint32_t qlow = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) qlow |= (((uint32_t)lane >> i) & 1u) << ((a.lanePos >> (4 * i)) & 15u);
+    const uint32_t g = qlow & 15u;
+    const uint32_t ownN = g == 0u ? 4u : (uint32_t)(__ffs((int)g) - 1);     // ancestors (depth >= D-6) whose tokens head my run
+    const uint32_t p0 = 2u * ownN, p1 = p0 + 2u;                           // bit of my root's token / of my first pair's
+    // my rows of the gather: gather bits 0-2 <- lane >> 3, 3-4 <- the store's index, 5-7 <- wave
+    uint32_t addrL = 0, byteL = 0, outL = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i == 3 || i == 4) continue;
+        const bool on = i < 3 ? ((lane >> (3 + i)) & 1) != 0 : ((wave >> (i - 5)) & 1) != 0;
+        addrL ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
+        byteL |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
+        outL += on ? a.gOut[i] : 0u;
+    }
+    // ---- the pipeline's bookkeeping (all wave-uniform)
+    uint32_t ops = 0;                       // vector-memory operations this wave has issued in the loop (DMAs and stores)
+    uint32_t markIdx[RG_IDXD];              // ... as of just after the index entries of a slot were requested,
+    uint32_t markP[RG_NP];                  // ... and just after the piece in a ring slot was.  "Done" = all but the (ops - mark)
+                                            // operations issued since are: loads return in issue order.  (Arrays indexed by
+                                            // unrolled compare-selects only: they stay in scalar registers.)
+    const auto mark_of_idx = [&](int slot) { uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < RG_IDXD; ++i) m = slot == i ? markIdx[i] : m;
+        return m; };
+    const auto mark_of_piece = [&](uint32_t p) { uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < RG_NP; ++i) m = (p & (RG_NP - 1)) == (uint32_t)i ? markP[i] : m;
+        return m; };
+#pragma unroll
+    for (int i = 0; i < RG_NP; ++i) markP[i] = 0;
+    const auto index_of = [&](int r) -> int64_t {       // first index entry of my emit block (the wave-th along x) of region r
+        const uint32_t rx = (uint32_t)r & ((1u << a.lrx) - 1u), ry = ((uint32_t)r >> a.lrx) & ((1u << a.lry) - 1u), rz = (uint32_t)r >> (a.lrx + a.lry);
+        const uint32_t blk = smw.blkTab[0][rx * 8u + (uint32_t)wave] | smw.blkTab[1][ry] | smw.blkTab[2][rz];
+        return (int64_t)brick * a.nIdx + ((int64_t)blk << 6);
     };
-    if (liveMask == 0ull) {
-        // an emit block under pruned nodes: one value per 64-leaf block, no stream, no further side-car
-        const uint32_t rep = val0 * 0x01010101u;
+    const auto request_index = [&](int r, int slot) {    // 256 + 64 bytes into index slot `slot`
+        const int64_t io = index_of(r);
+        RG_DMA("dword", a.idxOff + io + lane, idxOffLds + (uint32_t)slot * 256u);
+        if (lane < 16) RG_DMA("dword", (const uint32_t *)(a.idxVal + io) + lane, idxValLds + (uint32_t)slot * 64u);
+        ops += 2;
 #pragma unroll
-        for (int gg = 0; gg < 16; ++gg) buf[laneTerm ^ ((a.parkP[gg >> 2] >> (8 * (gg & 3))) & 255u)] = rep;
-    } else {
-        // ---- the string: from the first live 64-leaf block's root to (a bound on) the last one's end.  Known from the
-        // offsets alone, so the DMA starts beside the loads of the counts and depth-(D-3) scalars, not behind them
+        for (int i = 0; i < RG_IDXD; ++i) markIdx[i] = slot == i ? ops : markIdx[i];
+    };
+    const auto issue_piece = [&](uint32_t wbase, uint32_t p) {      // piece p of a string: words [wbase + 256 p, + 256) -> ring slot p mod RG_NP
+        const uint32_t w = wbase + 256u * p + 4u * (uint32_t)lane;
+        if (w + 4u <= capWords) RG_DMA("dwordx4", W + w, ringLds + (p & (RG_NP - 1)) * 1024u);
+        ++ops;
+#pragma unroll
+        for (int i = 0; i < RG_NP; ++i) markP[i] = (p & (RG_NP - 1)) == (uint32_t)i ? ops : markP[i];
+    };
+    // the staged state of a region
+    unsigned long long liveMask = 0ull;
+    uint32_t wbase = 0, totalPieces = 0, issued = 0, markSide = 0, offC = VR_IDX_DEAD, valC = 0;
+    // From the offsets alone: the string runs from the first live 64-leaf block's root to (a bound on) the last one's
+    // end.  Its first two pieces go to ring slots 0 and 1; the counts (1 KiB) and depth-(D-3) scalars (512 B) of the
+    // region land in slots 3 and 2, which the park reads before the string's pieces 2 and 3 are requested: a trip of
+    // two steps takes fewer than 512 words, so the first one never needs piece 2.
+    const auto stage = [&](int r, int slot) {
+        rg_vm_wait(ops - mark_of_idx(slot));
+        offC = smw.idxOff[wave][slot][lane];
+        valC = (smw.idxVal[wave][slot][lane >> 2] >> (8 * (lane & 3))) & 255u;
+        const bool liveL = offC != VR_IDX_DEAD;
+        liveMask = __ballot(liveL);
+        wbase = 0; totalPieces = 0; issued = 0;
+        if (liveMask == 0ull) return;
         const int firstL = __ffsll((long long)liveMask) - 1, lastL = 63 - __clzll((long long)liveMask);
-        const uint32_t firstOff = (uint32_t)__builtin_amdgcn_readlane((int)off, firstL), lastOff = (uint32_t)__builtin_amdgcn_readlane((int)off, lastL);
+        const uint32_t firstOff = (uint32_t)__builtin_amdgcn_readlane((int)offC, firstL), lastOff = (uint32_t)__builtin_amdgcn_readlane((int)offC, lastL);
         wbase = (firstOff >> 4) & ~3u;                                  // first word, 16-byte aligned
-        totalPieces = ((((lastOff + 575u + 15u) >> 4) - wbase) + 255u) >> 8;  // (a 64-leaf subtree is at most 63 + 64 * 8 tokens)
-        totalPieces = min(totalPieces, (capWords - wbase + 255u) >> 8);       // (every piece has a lane inside the buffer)
-        uint4 cv = make_uint4(0, 0, 0, 0);
-        uint2 sv = make_uint2(0, 0);
-        if (liveL) {
-            cv = *(const uint4 *)(a.fine + io * 16);
-            sv = *(const uint2 *)(a.val3 + io * 8);
-        }
+        const uint32_t tp = ((((lastOff + 575u + 15u) >> 4) - wbase) + 255u) >> 8;    // (a 64-leaf subtree is at most 63 + 64 * 8 tokens)
+        totalPieces = min(tp, (capWords - wbase + 255u) >> 8);                        // (every piece has a lane inside the buffer)
+        for (uint32_t p = 0; p < 2u && p < totalPieces; ++p) { issue_piece(wbase, p); ++issued; }
+        const int64_t io = index_of(r);
+        RG_DMA("dwordx4", a.fine + (io + lane) * 16, ringLds + 3u * 1024u);
+        if (lane < 32) RG_DMA("dwordx4", a.val3 + io * 8 + lane * 16, ringLds + 2u * 1024u);
+        ops += 2;
+        markSide = ops;
+    };
+    // ---- prologue: index entries of my first RG_IDXD regions, the first one staged
 #pragma unroll
-        for (int p = 0; p < RG_NP; ++p)
-            if ((uint32_t)p < totalPieces) { issue((uint32_t)p); ++issued; }
-        // ---- park, for each 4-leaf subtree of my 64-leaf block: the scalar of its depth-(D-3) parent (bits 0-7), the
-        // token position of its run relative to the ring's first word (8-23: prefix sum of the side-car counts) and
-        // whether its root exists (24: it owns more tokens than the ancestors heading its run -- a pruned ancestor ends
-        // the run).  A 64-leaf block under a pruned node parks its scalar with "no root" (or its final words, below).
-        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, sw[2] = {sv.x, sv.y};
-        // (a dead block whose whole step of four blocks is dead parks its final words: that step is skipped)
-        const bool stepDead = ((uint32_t)(liveMask >> (lane & 60)) & 15u) == 0u;
-        const uint32_t deadW = stepDead ? val0 * 0x01010101u : val0;
-        uint32_t run = liveL ? off - wbase * 16u : 0u;
+    for (int d = 0; d < RG_IDXD; ++d) markIdx[d] = 0;
 #pragma unroll
-        for (int gg = 0; gg < 16; ++gg) {
-            const uint32_t cgg = (cw[gg >> 2] >> (8 * (gg & 3))) & 255u;
-            const int own = gg == 0 ? 4 : (gg & 1 ? 0 : (gg & 2 ? 1 : (gg & 4 ? 2 : 3)));
-            const uint32_t vgg = (sw[gg >> 3] >> (8 * ((gg >> 1) & 3))) & 255u;
-            const uint32_t w = vgg | (run << 8) | ((uint32_t)(own - (int)cgg) & 0x01000000u);
-            buf[laneTerm ^ ((a.parkP[gg >> 2] >> (8 * (gg & 3))) & 255u)] = liveL ? w : deadW;
-            run += cgg;
-        }
-        mEnd = wave_incl_scan_max_dpp(liveL ? run : 0u);       // end of the last live block up to mine
-    }
-    __syncthreads();        // the tables
-    if (liveMask != 0ull) {
-        // ---- my role in a step: lane l <-> image word l of the step's 64
-        uint32_t qlow = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) qlow |= (((uint32_t)lane >> i) & 1u) << ((a.lanePos >> (4 * i)) & 15u);
-        const uint32_t g = qlow & 15u;
-        const uint32_t ownN = g == 0u ? 4u : (uint32_t)(__ffs((int)g) - 1);     // ancestors (depth >= D-6) whose tokens head my run
-        const uint32_t p0 = 2u * ownN, p1 = p0 + 2u;                           // bit of my root's token / of my first pair's
-#pragma unroll 1
-        for (int s = 0; s < 16; ++s) {
-            if ((((uint32_t)(liveMask >> (4 * s))) & 15u) == 0u) continue;       // (dead blocks parked their final words)
-            const uint32_t endTok = (uint32_t)__builtin_amdgcn_readlane((int)mEnd, 4 * s + 3);
-            // the pieces this step reads must have landed: DMAs retire in issue order
-            {
-                const int need = (int)((((endTok + 15u) >> 4) + 255u) >> 8);
-                const int allow = (int)issued - need;
-                if (allow <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (allow == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#if RG_NP > 2
-                else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    for (int d = 0; d < RG_IDXD; ++d) if (rid + d * G < nreg) request_index(rid + d * G, d);
+    stage(rid, 0);
+    int slot = 0;           // index slot of the current region
+#ifdef RG_STAMP             // (diagnostic build: where a wave's cycles go; never timed)
+    unsigned long long tAcc[6] = {0, 0, 0, 0, 0, 0};
+#define RG_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tAcc[i] += now_ - tLast; tLast = now_; } while (0)
+    unsigned long long tLast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tStart = tLast;
+#else
+#define RG_T(i) do { } while (0)
 #endif
-#if RG_NP > 4
-                else if (allow == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (allow == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else if (allow == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (allow == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-#endif
+    for (; rid < nreg; rid += G) {
+        RG_T(5);
+        if (liveMask == 0ull) {
+            // an emit block under pruned nodes: one value per 64-leaf block, no stream, no further side-car
+            const uint32_t rep = valC * 0x01010101u;
+#pragma unroll
+            for (int gg = 0; gg < 16; ++gg) buf[laneTerm ^ ((a.parkP[gg >> 2] >> (8 * (gg & 3))) & 255u)] = rep;
+            if (rid + RG_IDXD * G < nreg) request_index(rid + RG_IDXD * G, slot);
+        } else {
+            // ---- park, for each 4-leaf subtree of my 64-leaf block: the scalar of its depth-(D-3) parent (bits 0-7), the
+            // token position of its run relative to the ring's first word (8-23: prefix sum of the side-car counts) and
+            // whether its root exists (24: it owns more tokens than the ancestors heading its run -- a pruned ancestor
+            // ends the run).  A 64-leaf block under a pruned node parks its scalar with "no root", or, where its whole
+            // step of four blocks is dead (the step is skipped), its final words.
+            const bool liveL = offC != VR_IDX_DEAD;
+            rg_vm_wait(ops - markSide);
+            const uint4 cv = *(const uint4 *)(ringW + 768 + 4 * lane);
+            const uint2 sv = *(const uint2 *)(ringW + 512 + 2 * lane);
+            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, sw2[2] = {sv.x, sv.y};
+            const bool stepDead = ((uint32_t)(liveMask >> (lane & 60)) & 15u) == 0u;
+            const uint32_t deadW = stepDead ? valC * 0x01010101u : valC;
+            uint32_t run = liveL ? offC - wbase * 16u : 0u;
+#pragma unroll
+            for (int gg = 0; gg < 16; ++gg) {
+                const uint32_t cgg = (cw[gg >> 2] >> (8 * (gg & 3))) & 255u;
+                const int own = gg == 0 ? 4 : (gg & 1 ? 0 : (gg & 2 ? 1 : (gg & 4 ? 2 : 3)));
+                const uint32_t vgg = (sw2[gg >> 3] >> (8 * ((gg >> 1) & 3))) & 255u;
+                const uint32_t w = vgg | (run << 8) | ((uint32_t)(own - (int)cgg) & 0x01000000u);
+                buf[laneTerm ^ ((a.parkP[gg >> 2] >> (8 * (gg & 3))) & 255u)] = liveL ? w : deadW;
+                run += cgg;
             }
-            const uint32_t addr = (uint32_t)(64 * s) + ((uint32_t)lane ^ ((uint32_t)(s & 7) << 2));
-            const uint32_t pw = buf[addr];
-            const uint32_t rel = (pw >> 8) & 0xFFFFu, wi = rel >> 4, b = (rel & 15u) * 2u;
-            const uint32_t w0 = ringW[wi & RG_RING_MASK], w1 = ringW[(wi + 1u) & RG_RING_MASK],
-                           w2 = ringW[(wi + 2u) & RG_RING_MASK], w3 = ringW[(wi + 3u) & RG_RING_MASK];
-            const int V3 = (int)(pw & 255u);
-            const bool live = (pw & 0x01000000u) != 0u;
-            // my tokens: bits [0, 96) from my first token on
-            const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, b), hi = __builtin_amdgcn_alignbit(w2, w1, b),
-                           hh = __builtin_amdgcn_alignbit(w3, w2, b);
-            const uint32_t c4 = live ? __builtin_amdgcn_ubfe(lo, p0, 2) : 3u;      // my depth-(D-2) root (behind the ancestors' tokens)
-            const int V4 = med3i(V3 + *(const int *)((const char *)sm.d4 + (c4 << 2)), 0, 255);
-            const uint32_t dead3 = c4 == 3u ? 3u : 0u;
-            uint32_t used1, used2;
-            const uint32_t b01 = rg_pair(__builtin_amdgcn_alignbit(hi, lo, p1), __builtin_amdgcn_alignbit(hh, hi, p1), dead3, V4, sm, used1);
-            const uint32_t p2 = p1 + used1;                   // <= 10 + 34
-            const bool q = p2 >= 32u;
-            const uint32_t A_ = q ? hi : lo, B_ = q ? hh : hi, C_ = q ? 0u : hh;
-            const uint32_t b23 = rg_pair(__builtin_amdgcn_alignbit(B_, A_, p2), __builtin_amdgcn_alignbit(C_, B_, p2), dead3, V4, sm, used2);
-            buf[addr] = b01 | (b23 << 16);
-            // refill: the slot of piece p is free once every word of piece p - RG_NP lies before the next step's first
-            // (a step takes fewer than 256 words, so one refill per step keeps up; two leave slack)
-            const uint32_t consumedWord = endTok >> 4;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                if (issued >= RG_NP && issued < totalPieces && 256u * (issued - (RG_NP - 1)) <= consumedWord) { issue(issued); ++issued; }
+            const uint32_t mEnd = wave_incl_scan_max_dpp(liveL ? run : 0u);       // end of the last live block up to mine
+            RG_T(1);
+            // the side-cars are in registers: their ring slots take the string's pieces 2 and 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (uint32_t p = 2; p < (uint32_t)RG_NP && p < totalPieces; ++p) { issue_piece(wbase, p); ++issued; }
+            if (rid + RG_IDXD * G < nreg) request_index(rid + RG_IDXD * G, slot);
+            uint32_t guardNext = RG_NP;          // next piece that lands on the ring's first slot (its first words feed the guard)
+            uint32_t landed = 0;                 // pieces known to have landed
+#pragma unroll 1
+            for (int t = 0; t < 8; ++t) {       // two steps per trip: their chains are independent, the scheduler interleaves them
+                const uint32_t nib = ((uint32_t)(liveMask >> (8 * t))) & 255u;
+                if (nib == 0u) continue;       // (dead blocks parked their final words)
+                const uint32_t endTok = (uint32_t)__builtin_amdgcn_readlane((int)mEnd, 8 * t + 7);
+                // the pieces this trip reads must have landed
+                const uint32_t need = (((endTok + 15u) >> 4) + 255u) >> 8;
+                if (need > landed) {
+                    rg_vm_wait(ops - mark_of_piece(need - 1u));
+                    landed = need;
+                    while (guardNext < need) {     // a piece has landed on the ring's first slot: its first four words again behind the last slot
+                        if (lane < 4) ringW[RG_NP * 256 + lane] = ringW[lane];
+                        guardNext += RG_NP;
+                    }
+                }
+                const uint32_t sw = (uint32_t)((2 * t) & 7) << 2;
+                const uint32_t addr0 = (uint32_t)(128 * t) + ((uint32_t)lane ^ sw), addr1 = (uint32_t)(128 * t + 64) + ((uint32_t)lane ^ (sw | 4u));
+                if ((nib & 15u) != 0u && (nib >> 4) != 0u) {
+                    const uint32_t pw0 = buf[addr0], pw1 = buf[addr1];
+                    const uint32_t *r0 = ringW + ((pw0 >> 12) & RG_RING_MASK), *r1 = ringW + ((pw1 >> 12) & RG_RING_MASK);
+                    const uint32_t x0 = r0[0], x1 = r0[1], x2 = r0[2], x3 = r0[3];
+                    const uint32_t y0 = r1[0], y1 = r1[1], y2 = r1[2], y3 = r1[3];
+                    const uint32_t q0 = rg_quad(pw0, x0, x1, x2, x3, p0, p1, sm), q1 = rg_quad(pw1, y0, y1, y2, y3, p0, p1, sm);
+                    buf[addr0] = q0;
+                    buf[addr1] = q1;
+                } else {
+                    const uint32_t addr = (nib & 15u) != 0u ? addr0 : addr1;
+                    const uint32_t pw0 = buf[addr];
+                    const uint32_t *r0 = ringW + ((pw0 >> 12) & RG_RING_MASK);
+                    const uint32_t x0 = r0[0], x1 = r0[1], x2 = r0[2], x3 = r0[3];
+                    buf[addr] = rg_quad(pw0, x0, x1, x2, x3, p0, p1, sm);
+                }
+                // refill: the slot of piece p is free once every word of piece p - RG_NP lies before the next trip's first
+                // (a trip takes fewer than 512 words: three refills keep up with two to spare)
+                const uint32_t consumedWord = endTok >> 4;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this trip's ring reads are back)
+                while (issued < totalPieces && 256u * (issued - (RG_NP - 1)) <= consumedWord) { issue_piece(wbase, issued); ++issued; }
+            }
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no LDS-DMA may outlive the workgroup's LDS)
-    __syncthreads();
-    // ---- gather: a 16-byte row piece of emit block c = lane & 7 per lane, eight whole 128-byte lines per store
-    {
-        const int c = lane & 7;
-        const uint32_t *img = sm.buf + c * RG_BLK_WORDS;
-        uint8_t *O = a.out + (int64_t)brick * a.voxels + ((int64_t)rz * 16 * a.Y + (int64_t)ry * 16) * a.X + (int64_t)rx * 128 + c * 16;
-        // gather bits 0-2 <- lane >> 3, 3-4 <- the store's index, 5-7 <- wave
-        uint32_t addrL = 0, byteL = 0, outL = 0;
+        RG_T(2);
+        // ---- where this region's voxels go
+        const uint32_t rxC = (uint32_t)rid & ((1u << a.lrx) - 1u), ryC = ((uint32_t)rid >> a.lrx) & ((1u << a.lry) - 1u), rzC = (uint32_t)rid >> (a.lrx + a.lry);
+        uint8_t *O = a.out + (int64_t)brick * a.voxels + ((int64_t)rzC * 16 * a.Y + (int64_t)ryC * 16) * a.X + (int64_t)rxC * 128 + (lane & 7) * 16;
+        // ---- the pipeline: the next region staged (the ring is free now; a stale piece of this region still in flight
+        // lands before the next region's piece for the same slot: loads return in issue order)
+        slot = slot + 1 == RG_IDXD ? 0 : slot + 1;
+        if (rid + G < nreg) stage(rid + G, slot);
+        RG_T(2);
+        rg_barrier();           // every block of the region is decoded
+        RG_T(3);
+        // ---- gather: a 16-byte row piece of emit block c = lane & 7 per lane, eight whole 128-byte lines per store.
+        // All reads of the image first (they are independent), then the byte picks and the stores.
+        {
+            const uint32_t *img = sm.buf + (lane & 7) * RG_BLK_WORDS;
+            const uint32_t xr1 = a.xRead[0] >> 16, xr2 = a.xRead[1] & 0xFFFFu, xr3 = a.xRead[1] >> 16;
+            uint32_t addrI[4], bselI[4], ooI[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const bool on = ((lane >> (3 + i)) & 1) != 0;
-            addrL ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
-            byteL |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
-            outL += on ? a.gOut[i] : 0u;
-        }
+            for (int it = 0; it < 4; ++it) {
+                uint32_t addr = addrL, bsel = byteL, oo = outL;
 #pragma unroll
-        for (int i = 5; i < 8; ++i) {
-            const bool on = ((wave >> (i - 5)) & 1) != 0;
-            addrL ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
-            byteL |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
-            outL += on ? a.gOut[i] : 0u;
-        }
-        const uint32_t xr1 = a.xRead[0] >> 16, xr2 = a.xRead[1] & 0xFFFFu, xr3 = a.xRead[1] >> 16;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            uint32_t addr = addrL, bsel = byteL, oo = outL;
-#pragma unroll
-            for (int i = 3; i < 5; ++i) {
-                const bool on = ((it >> (i - 3)) & 1) != 0;
-                addr ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
-                bsel |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
-                oo += on ? a.gOut[i] : 0u;
+                for (int i = 3; i < 5; ++i) {
+                    const bool on = ((it >> (i - 3)) & 1) != 0;
+                    addr ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
+                    bsel |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
+                    oo += on ? a.gOut[i] : 0u;
+                }
+                addrI[it] = addr; bselI[it] = bsel; ooI[it] = oo;
             }
             if (a.jx < 2) {          // x bit 0 lives in the byte index: a word holds two x-neighbours
-                const uint32_t b0 = bsel, b1 = bsel | (1u << a.jx);
-                const uint32_t sel = b0 | (b1 << 8) | ((4u + b0) << 16) | ((4u + b1) << 24);
-                const uint4 P = *(const uint4 *)(img + addr), Q = *(const uint4 *)(img + (addr ^ xr1));
-                store_out16(O + oo, make_uint4(__builtin_amdgcn_perm(P.y, P.x, sel), __builtin_amdgcn_perm(P.w, P.z, sel),
-                                               __builtin_amdgcn_perm(Q.y, Q.x, sel), __builtin_amdgcn_perm(Q.w, Q.z, sel)));
+                uint4 P[4], Q[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { P[it] = *(const uint4 *)(img + addrI[it]); Q[it] = *(const uint4 *)(img + (addrI[it] ^ xr1)); }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const uint32_t b0 = bselI[it], b1 = b0 | (1u << a.jx);
+                    const uint32_t sel = b0 | (b1 << 8) | ((4u + b0) << 16) | ((4u + b1) << 24);
+                    const uint4 o4 = make_uint4(__builtin_amdgcn_perm(P[it].y, P[it].x, sel), __builtin_amdgcn_perm(P[it].w, P[it].z, sel),
+                                                __builtin_amdgcn_perm(Q[it].y, Q[it].x, sel), __builtin_amdgcn_perm(Q[it].w, Q[it].z, sel));
+#ifdef RG_KO_STORE          // (timing experiments: no store; the count of operations must stay right)
+                    asm volatile("" :: "v"(o4.x), "v"(o4.y), "v"(o4.z), "v"(o4.w));
+#else
+                    store_out16(O + ooI[it], o4);
+                    ++ops;
+#endif
+                }
             } else {                 // jx == 2: four x-neighbours in four words
-                const uint32_t sel = bsel | ((4u + bsel) << 8) | 0x0c0c0000u;
-                const uint4 P = *(const uint4 *)(img + addr), Q = *(const uint4 *)(img + (addr ^ xr1)),
-                            R = *(const uint4 *)(img + (addr ^ xr2)), T = *(const uint4 *)(img + (addr ^ xr3));
-                const auto mk = [sel](const uint4 &u) {
-                    return __builtin_amdgcn_perm(__builtin_amdgcn_perm(u.w, u.z, sel), __builtin_amdgcn_perm(u.y, u.x, sel), 0x05040100u);
-                };
-                store_out16(O + oo, make_uint4(mk(P), mk(Q), mk(R), mk(T)));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint4 P[2], Q[2], R[2], T[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t ad = addrI[2 * h + k];
+                        P[k] = *(const uint4 *)(img + ad); Q[k] = *(const uint4 *)(img + (ad ^ xr1));
+                        R[k] = *(const uint4 *)(img + (ad ^ xr2)); T[k] = *(const uint4 *)(img + (ad ^ xr3));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t bsel = bselI[2 * h + k];
+                        const uint32_t sel = bsel | ((4u + bsel) << 8) | 0x0c0c0000u;
+                        const auto mk = [sel](const uint4 &u) {
+                            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(u.w, u.z, sel), __builtin_amdgcn_perm(u.y, u.x, sel), 0x05040100u);
+                        };
+                        const uint4 o4 = make_uint4(mk(P[k]), mk(Q[k]), mk(R[k]), mk(T[k]));
+#ifdef RG_KO_STORE
+                        asm volatile("" :: "v"(o4.x), "v"(o4.y), "v"(o4.z), "v"(o4.w));
+#else
+                        store_out16(O + ooI[2 * h + k], o4);
+                        ++ops;
+#endif
+                    }
+                }
             }
         }
+        RG_T(4);
+        rg_barrier();           // the image is free for the next region's park
     }
+#ifdef RG_STAMP
+    RG_T(5);
+    if (lane == 0 && a.dbg) {
+        atomicAdd(&a.dbg[0], __builtin_amdgcn_s_memtime() - tStart);
+        for (int i = 1; i < 6; ++i) atomicAdd(&a.dbg[i], tAcc[i]);
+        atomicAdd(&a.dbg[6], 1ull);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no LDS-DMA may outlive the workgroup's LDS)
 }
 
 static bool tile_geometry(const BrickSet *bs, TileArgs &a)
@@ -1614,6 +1803,15 @@ static bool region_geometry(const BrickSet *bs, RegionArgs &a)
     a.X = g.X; a.Y = g.Y; a.voxels = g.voxels;
     a.lrx = 0; while ((128 << a.lrx) < g.X) ++a.lrx;
     a.lry = 0; while ((16 << a.lry) < g.Y) ++a.lry;
+    a.nreg = (g.X / 128) * (g.Y / 16) * (g.Z / 16);
+    // the emit block of a 16^3 box: the rank bits above the twelve lowest
+    uint32_t bpos[3] = {0, 0, 0};
+    for (int d = 0; d < D - 12; ++d) {
+        const int ax = g.axis[d], kb = g.bit[d] - 4;       // coordinate bit kb + 4 of axis ax sits at rank bit D - 1 - d
+        if (kb < 0 || kb >= 6) return false;
+        bpos[ax] |= (uint32_t)(D - 1 - d - 12) << (5 * kb);
+    }
+    a.blkX = bpos[0]; a.blkY = bpos[1]; a.blkZ = bpos[2];
     return true;
 }
 
@@ -1686,8 +1884,24 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
             r.tree = sm.tree; r.treeCap = bs->treeCap;
             r.idxOff = bs->idxOff; r.idxVal = idxVals; r.fine = bs->fineIdx; r.val3 = bs->idxVal3; r.nIdx = bs->nIdx;
             r.ctrls = sm.ctrl; r.out = out; r.spread = bs->spread; r.D = bs->D; r.cut = cut;
-            const unsigned regions = (unsigned)((bs->g.X / 128) * (bs->g.Y / 16) * (bs->g.Z / 16));
-            hipLaunchKernelGGL(k_decode_region, dim3(regions, bs->B), dim3(64 * RG_WAVES), 0, st, r);
+            // a workgroup decodes every RG_PER-th region of its brick: enough regions to amortise its tables and the
+            // pipeline's fill, enough workgroups (a few thousand for the bench volume) to balance the chip
+            r.dbg = nullptr;
+#ifdef RG_STAMP
+            {
+                static unsigned long long *dbgDev = nullptr;
+                if (!dbgDev) { hipMalloc(&dbgDev, 64); hipMemset(dbgDev, 0, 64); }
+                unsigned long long h[8];
+                hipMemcpy(h, dbgDev, 64, hipMemcpyDeviceToHost);
+                if (h[6]) fprintf(stderr, "[rg stamp] waves %llu  cycles/wave: total %.0f park %.0f steps+stage %.0f barrier1 %.0f gather %.0f barrier2+top %.0f\n", h[6],
+                                  (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+                hipMemset(dbgDev, 0, 64);
+                r.dbg = dbgDev;
+            }
+#endif
+            unsigned wgs = (unsigned)((r.nreg + RG_PER - 1) / RG_PER);
+            if ((int64_t)wgs * bs->B < 2048) wgs = (unsigned)std::min<int64_t>(r.nreg, (2048 + bs->B - 1) / bs->B);
+            hipLaunchKernelGGL(k_decode_region, dim3(wgs, bs->B), dim3(64 * RG_WAVES), 0, st, r);
         } else if (useQuad) {
             const int levels = cut - bs->D < 0 ? 0 : (cut - bs->D > VR_CHAIN_LEVELS ? VR_CHAIN_LEVELS : cut - bs->D);
             // one table per number of refining levels, all written once: two decodes of one set on different streams at
