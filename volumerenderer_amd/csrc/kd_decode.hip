@@ -1195,7 +1195,7 @@ k_decode_quad(TileArgs a)
 #define RG_MINW 4           // waves per SIMD asked of the register allocator (4: two workgroups per CU, 6: three)
 #endif
 #ifndef RG_PER
-#define RG_PER 32           // regions per workgroup
+#define RG_PER 16           // regions per workgroup
 #endif
 #define RG_WAVES 8
 #define RG_BLK_WORDS 1028
@@ -1249,10 +1249,9 @@ __device__ __forceinline__ void rg_barrier()
 }
 
 struct RegionShared {
-    uint32_t chainA[256];           // LDS address 0: branch tokens 1-4 -> LO | A << 8 | HI << 16
-    uint32_t chainB[64];            // branch tokens 5-7
+    uint32_t leafA[1024];           // LDS address 0: a leaf's code + branch tokens 1-4 -> A (16 bits) | LO << 16 | HI << 24
+    uint32_t chainB[64];            // branch tokens 5-7 -> A (16 bits) | LO << 16 | HI << 24
     int d4[4], d5[4];               // 0 / +d / -d / 0 per token at depths D-2, D-1
-    uint32_t d6p[16];               // the same for the two leaf codes of a pair, packed 16-bit lanes, keyed c1 | c2 << 2
     uint32_t buf[RG_WAVES * RG_BLK_WORDS];
     uint32_t ring[RG_WAVES][RG_NP * 256 + 4];      // + 4: the ring's first words again (a lane reads 4 consecutive words)
 };
@@ -1277,20 +1276,20 @@ __device__ __forceinline__ uint32_t rg_pair(uint32_t y, uint32_t yh, uint32_t de
     const uint32_t f2 = ffbl_u32(yl2 & (yl2 >> 1) & 0x5555u) & keep;
     const uint32_t e2 = min(f2, 14u);
     const uint32_t ym2 = ones_from(f2, yl2);
-    // both leaves in packed 16-bit lanes: V5 + code step, then the two composed clamp-adds of the branch.  A leaf's
-    // own clamp to [0, 255] is absorbed by the first table's (f monotone, f(0) = LO, f(255) = HI: k_decode_quad)
-    const uint32_t dl = *(const uint32_t *)((const char *)sm.d6p + (((ym1 & 3u) | ((ym2 & 3u) << 2)) << 2));
-    const uint32_t a1 = *(const uint32_t *)((const char *)sm.chainA + (ym1 & 0x3FCu));
-    const uint32_t a2 = *(const uint32_t *)((const char *)sm.chainA + (ym2 & 0x3FCu));
+    // both leaves in packed 16-bit lanes: the two composed clamp-adds v -> min(max(v + A, LO), HI).  The first table
+    // takes the leaf's code with branch tokens 1-4: the code's own step clamps to [0, 255] before the branch runs, and
+    // clamp-adds compose to clamp-adds, so (code, tokens 1-4) is one entry keyed by ten bits of the window
+    const uint32_t a1 = *(const uint32_t *)((const char *)sm.leafA + ((ym1 << 2) & 0xFFCu));
+    const uint32_t a2 = *(const uint32_t *)((const char *)sm.leafA + ((ym2 << 2) & 0xFFCu));
     const uint32_t b1 = *(const uint32_t *)((const char *)sm.chainB + ((ym1 >> 8) & 0xFCu));
     const uint32_t b2 = *(const uint32_t *)((const char *)sm.chainB + ((ym2 >> 8) & 0xFCu));
-    vr_s16x2 v = pk_s((uint32_t)V5 * 0x10001u) + pk_s(dl);
-    v = v + pk_s(__builtin_amdgcn_perm(a2, a1, 0x0A050801u));                               // A: byte 1, sign-extended
-    v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(a2, a1, 0x0C040C00u)));     // LO: byte 0
-    v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(a2, a1, 0x0C060C02u)));     // HI: byte 2
-    v = v + pk_s(__builtin_amdgcn_perm(b2, b1, 0x0A050801u));
-    v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C040C00u)));
-    v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C060C02u)));
+    vr_s16x2 v = pk_s((uint32_t)V5 * 0x10001u);
+    v = v + pk_s(__builtin_amdgcn_perm(a2, a1, 0x05040100u));                               // A: low halves
+    v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(a2, a1, 0x0C060C02u)));     // LO: byte 2
+    v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(a2, a1, 0x0C070C03u)));     // HI: byte 3
+    v = v + pk_s(__builtin_amdgcn_perm(b2, b1, 0x05040100u));
+    v = __builtin_elementwise_max(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C060C02u)));
+    v = __builtin_elementwise_min(v, pk_s(__builtin_amdgcn_perm(b2, b1, 0x0C070C03u)));
     used = pr ? 2u : e1 + e2 + 6u;
     return __builtin_amdgcn_perm(0, pk_u(v), 0x0C0C0200u);
 }
@@ -1377,34 +1376,37 @@ k_decode_region(RegionArgs a)
             for (int k = 0; k < 6; ++k) r |= (((uint32_t)v >> k) & 1u) << ((pos >> (5 * k)) & 31u);
             smw.blkTab[ax][v] = r;
         }
-        if (t < 320) {
-            const int first = t < 256 ? 0 : 4, n = t < 256 ? 4 : 3, idx = t < 256 ? t : t - 256;
-            int dist[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int depth = a.D + 1 + first + q; dist[q] = (q < n && depth <= a.cut) ? dmap[depth] : 0; }
+        // a clamp-add f(v) = min(max(v + A, LO), HI) with LO = f(0), HI = f(255); steps: [0, 255]-clamped adds
+        const auto compose = [](int tok0, bool withCode, int d0, const int *dist, int n, uint32_t key) {
             int A = 0, LO = 0, HI = 255;
             bool go = true;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tok = (idx >> (2 * q)) & 3;
-                go = go && q < n && tok != 3;
-                const int dl = !go ? 0 : (tok == 1 ? dist[q] : (tok == 2 ? -dist[q] : 0));
-                A += dl;
-                LO = min(max(LO + dl, 0), 255);
-                HI = min(max(HI + dl, 0), 255);
+            if (withCode) {
+                go = tok0 != 3;                 // a pruned leaf: nothing follows
+                const int dl = tok0 == 1 ? d0 : (tok0 == 2 ? -d0 : 0);
+                A += dl; LO = min(max(LO + dl, 0), 255); HI = min(max(HI + dl, 0), 255);
             }
-            const uint32_t ent = (uint32_t)LO | ((uint32_t)(A & 255) << 8) | ((uint32_t)HI << 16);
-            if (t < 256) sm.chainA[idx] = ent; else sm.chainB[idx] = ent;
+            for (int q = 0; q < n; ++q) {
+                const int tok = (int)((key >> (2 * q)) & 3u);
+                go = go && tok != 3;
+                const int dl = !go ? 0 : (tok == 1 ? dist[q] : (tok == 2 ? -dist[q] : 0));
+                A += dl; LO = min(max(LO + dl, 0), 255); HI = min(max(HI + dl, 0), 255);
+            }
+            return ((uint32_t)A & 0xFFFFu) | ((uint32_t)LO << 16) | ((uint32_t)HI << 24);
+        };
+        {
+            int distA[4], distB[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int depth = a.D + 1 + q; distA[q] = depth <= a.cut ? dmap[depth] : 0; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const int depth = a.D + 5 + q; distB[q] = depth <= a.cut ? dmap[depth] : 0; }
+            const int d6 = a.D <= a.cut ? dmap[a.D] : 0;
+            for (int e = t; e < 1024; e += 64 * RG_WAVES) sm.leafA[e] = compose(e & 3, true, d6, distA, 4, (uint32_t)e >> 2);
+            if (t < 64) sm.chainB[t] = compose(0, false, 0, distB, 3, (uint32_t)t);
         }
         if (t < 8) {
             const int lv = t >> 2, tok = t & 3, depth = a.D - 2 + lv;
             const int dist = depth <= a.cut ? dmap[depth] : 0;
             (lv ? sm.d5 : sm.d4)[tok] = tok == 1 ? dist : (tok == 2 ? -dist : 0);
-        } else if (t < 24) {
-            const int k = t - 8, c1 = k & 3, c2 = k >> 2;
-            const int dist = a.D <= a.cut ? dmap[a.D] : 0;
-            const int s1 = c1 == 1 ? dist : (c1 == 2 ? -dist : 0), s2 = c2 == 1 ? dist : (c2 == 2 ? -dist : 0);
-            sm.d6p[k] = ((uint32_t)s1 & 0xFFFFu) | ((uint32_t)s2 << 16);
         }
     }
     rg_barrier();           // the tables
