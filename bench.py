@@ -317,6 +317,7 @@ def main():
     ap.add_argument("--level-loop-streams", type=int, default=2, choices=[1, 2, 3, 4],
                     help="vr_brickset_set_concurrency for the strictly serial pass (library default 2; 1 for clean "
                          "per-kernel profiles).  The pipelined sets always use 1")
+    ap.add_argument("--no-extra-timing", action="store_true", help="skip the second timed pass (value_no_compact)")
     ap.add_argument("--composite", action="store_true",
                     help="N > 1 only: also time a sort-last composited 1080p frame over RCCL (off by default: a "
                          "collective that fails on one rank must never hang the headline measurement)")
@@ -433,6 +434,29 @@ def main():
         dt = float(tt.item())
     total_vox = float(V) * B * world * args.steps
     value = total_vox / dt / 1e6
+    # the same steps without the contiguous copy of the compressed stream at the end of build() (vr_brickset_set_compaction:
+    # a pipeline that only decodes on the device may leave it to the first get_tree / save): reported beside `value`, never as it
+    value_nc = None
+    if not args.no_extra_timing:
+        for s_ in sets:
+            s_.set_compaction(False)
+        run_steps(min(args.warmup, NS))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_nc = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_nc], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_nc = float(tt.item())
+        value_nc = total_vox / dt_nc / 1e6
+        for s_ in sets:
+            s_.set_compaction(True)
     outs = None                        # the extra output volumes are not needed any more
     torch.cuda.empty_cache()
 
@@ -471,10 +495,24 @@ def main():
             traffic = pm["decode_traffic_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "k_decode_quad", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "k_decode_region", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": PMC_TRAFFIC + " (bytes per launch)" if traffic else None,
                 "alg_bytes_per_launch": alg, "avg_launch_ms": round(dec_avg_s * 1e3, 4)}
+
+    # the encoder as a whole against the same roof: algorithmic bytes of a build = the voxels read + the stream written
+    enc_avg_s = sum(enc_ms) / len(enc_ms) / 1e3
+    enc_alg = alg                       # V + tree bytes (+ distanceMap) per brick: the same sum, read and written the other way round
+    enc_traffic = None
+    try:
+        if traffic is not None:
+            enc_traffic = pm.get("encode_traffic_bytes_per_build")
+    except Exception:
+        pass
+    roofline_encode = {"bound": "hbm", "kernels": "one build() = pyramid + level loop + prune/emit + index + compaction",
+                       "achieved": round(enc_alg / enc_avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(enc_alg / enc_avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": enc_traffic,
+                       "alg_bytes_per_build": enc_alg, "avg_build_ms": round(enc_avg_s * 1e3, 3)}
 
     res = {"metric": "Mvoxels/s kd-tree compress+decode", "value": round(value, 2), "unit": "Mvoxels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -492,7 +530,8 @@ def main():
            "serial_ms_per_step": round(sum(enc_ms) / len(enc_ms) + dec_avg_s * 1e3, 3),
            "encode_ms": round(sum(enc_ms) / len(enc_ms), 3), "decode_ms": round(dec_avg_s * 1e3, 3),
            "phases_ms": {k: round(v, 3) for k, v in phases.items()},
-           "roofline": roofline}
+           "value_no_compact": round(value_nc, 2) if value_nc else None,
+           "roofline": roofline, "roofline_encode": roofline_encode}
 
     if not args.no_render and not args.bricks and rank == 0:
         # 1080p frames of the decoded volume on a camera orbit: raycaster.frag and isosurface.frag, each also with the

@@ -260,6 +260,15 @@ vr_status vr_brickset_last_timings(vr_brickset *bs, float phases_ms[5]);
  * Results do not depend on it.  MidRangeTree sets always run their two streams' level loops side by side. */
 vr_status vr_brickset_set_concurrency(vr_brickset *bs, int32_t level_loop_streams);
 
+/* ---- the contiguous stream (R.cpp:631-718, tree.swap(preorderTree)) ----------------------------------------------
+ * A build of a brick of 4096 leaves or more keeps every 4096-leaf block's token string in a slot of its own (what the
+ * decoders read, in place) and, as its last step, writes the reference's contiguous byte stream beside it: the bytes
+ * vr_brickset_get_tree / save / get_packed4 hand out.  on_build = 0 leaves that copy to the first call that asks for
+ * bytes (a pipeline that only ever decodes on the device saves ~4 % of a build); 1 (default) is the reference's build().
+ * The contiguous streams of all bricks lie back to back in one buffer sized from their real lengths (about 0.6 byte
+ * per voxel for the bench volume), regrown on demand. */
+vr_status vr_brickset_set_compaction(vr_brickset *bs, int32_t on_build);
+
 /* ---- debugging switches (new) ----------------------------------------------------------------------------------
  * Which kernel serves a call is decided by the set's geometry and by a few switches kept IN THE HANDLE: they are
  * initialised from the environment (VRHIP_DECODE_WALK, VRHIP_DECODE_FINE_V1, VRHIP_DECODE_QUAD, VRHIP_DECODE_V1,

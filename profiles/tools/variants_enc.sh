@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage: profiles/tools/variants_enc.sh "<hipcc flags>" ... : encode timing per build variant
-for v in "$@"; do
-  export VRHIP_EXTRA_HIPCC_FLAGS="$v"
-  rm -f /root/repo/volumerenderer_amd/libvrhip.so
-  TAG="[$v]" python /root/repo/profiles/tools/enc_time.py 2>&1 | grep -v amdgpu.ids | tail -2
+# usage: profiles/tools/variants_enc.sh "flagsA" "flagsB" ...   (each variant rebuilds libvrhip.so and times the build phases)
+cd /root/repo
+for f in "$@"; do
+  echo "=== variant: $f"
+  VRHIP_EXTRA_HIPCC_FLAGS="$f" TAG="$f" timeout -k 10 400 python profiles/tools/enc_time.py 2>&1 | grep -v "amdgpu.ids\|warning\|^ *[0-9]* |\|^ *|\|generated"
 done

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vr_brickset_last_timings": (_I32, [_P, C.POINTER(C.c_float)]),
     "vr_brickset_set_concurrency": (_I32, [_P, C.c_int32]),
     "vr_brickset_set_switch": (_I32, [_P, C.c_char_p, C.c_int32]),
+    "vr_brickset_set_compaction": (_I32, [_P, C.c_int32]),
     "vr_debug_set": (_I32, [C.c_char_p, C.c_int32]),
 }
 

@@ -64,6 +64,10 @@ class BrickSet:
     def set_max_epochs(self, e):
         check(self._L.vr_brickset_set_max_epochs(self._h, int(e)), "setMaxEpochs")
 
+    def set_compaction(self, on_build=True):
+        """build() ends with the reference's contiguous stream (default) or leaves it to the first get_tree / save."""
+        check(self._L.vr_brickset_set_compaction(self._h, 1 if on_build else 0), "vr_brickset_set_compaction")
+
     def set_switch(self, name, value=1):
         """Debugging switch of this set (vr_brickset_set_switch): which kernel serves the next calls."""
         check(self._L.vr_brickset_set_switch(self._h, name.encode(), int(value)), "vr_brickset_set_switch(%s)" % name)

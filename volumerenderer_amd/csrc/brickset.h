@@ -13,7 +13,8 @@ struct Stream2 {              // one 2-bit stream (mid, or MidRangeTree's half-r
     Ctrl *ctrl = nullptr;     // B
     uint8_t *tree = nullptr;  // B * treeCap      the stream the decoders read: the reference's contiguous preorder stream (TwoBitArray
                               //                  packing) or, after a fused build, its block-gapped form (BrickSet::gapped)
-    uint8_t *treeCompact = nullptr; // B * treeCap  fused builds: the contiguous stream, made on demand (compact_launch)
+    uint8_t *treeCompact = nullptr; // BrickSet::compactCap bytes: fused builds: the reference's contiguous streams, brick b at byte
+                                    // BrickSet::brickOff[b] (compact_launch; at the end of build() unless compaction was turned off)
 };
 
 // Debugging / experiment switches.  Read from the environment (VRHIP_<NAME>) ONCE, when a set is created, or set
@@ -91,7 +92,12 @@ struct BrickSet {
     bool encoderReady = false;  // every buffer of ensure_encoder_buffers (capi.hip) is allocated
     bool built = false, hostCtrlValid = false;
     bool gapped = false;        // mid.tree / rng.tree hold 4096-leaf block strings in fixed slots (kd_encode.hip PE_WORDS)
-    bool compactValid = false;  // treeCompact holds the current build's contiguous stream
+    bool compactValid = false;  // treeCompact holds the current build's contiguous stream (unless compactOverflow says it did not fit)
+    bool compactOnBuild = true; // build() ends with the contiguous stream, like the reference's (tree.swap(preorderTree), R.cpp:714-718)
+    int64_t compactCap = 0;     // bytes of each treeCompact buffer: sized from the streams' real lengths, not from their worst case
+    unsigned long long *brickOff = nullptr;   // B + 1 (device): byte offset of every brick's stream in treeCompact (16-byte aligned); [B] = total
+    int32_t *compactOverflow = nullptr;       // device flag: the streams did not fit compactCap (nothing was written; the host regrows and repeats)
+    std::vector<unsigned long long> hostBrickOff;
     bool foreign = false;       // stream installed by set_tree/open (no encoder state)
     std::vector<int64_t> openTreeBytes; // per brick: tree.bits size as the reference's open() would have it
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

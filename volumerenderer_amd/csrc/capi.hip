@@ -204,6 +204,7 @@ vr_status vr_brickset_destroy(vr_brickset *h)
     free_encoder_buffers(b);
     free_stream2(b.mid);
     free_stream2(b.rng);
+    hipFree(b.brickOff); hipFree(b.compactOverflow);
     hipFree(b.idxOff); hipFree(b.idxVal); hipFree(b.idxValCut); hipFree(b.fineIdx); hipFree(b.idxVal3); hipFree(b.chainTab); hipFree(b.decTables); hipFree(b.lut); hipFree(b.spread); hipFree(b.srcIdx); hipFree(b.ownerRank); hipFree(b.ownerSurv); hipFree(b.rankVals);
     for (int i = 0; i < 8; ++i) if (b.ev[i]) hipEventDestroy(b.ev[i]);
     if (b.evFork) hipEventDestroy(b.evFork);
@@ -330,6 +331,13 @@ vr_status vr_brickset_set_switch(vr_brickset *h, const char *name, int32_t value
     return VR_OK;
 }
 
+vr_status vr_brickset_set_compaction(vr_brickset *h, int32_t on_build)
+{
+    if (!h) return VR_ERR_INVALID;
+    h->s.compactOnBuild = on_build != 0;
+    return VR_OK;
+}
+
 vr_status vr_debug_set(const char *name, int32_t value)
 {
     if (!name) return VR_ERR_INVALID;
@@ -357,6 +365,7 @@ vr_status vr_brickset_build(vr_brickset *h, const uint8_t *vox, void *stream)
     vr_status rc = ensure_encoder_buffers(b);
     if (rc != VR_OK) return rc;
     b.hostCtrlValid = false;
+    b.hostBrickOff.clear();
     b.foreign = false;
     std::fill(b.openTreeBytes.begin(), b.openTreeBytes.end(), -1);
     {   // -3: a lazily allocated side buffer did not fit
@@ -412,26 +421,43 @@ vr_status vr_brickset_info(vr_brickset *h, int32_t brick, vr_tree_info *info)
     return VR_OK;
 }
 
-// The contiguous preorder stream (the reference's tree.bits) of stream s: after a fused build the device holds the
-// block-gapped form the decoders read; the reference's layout is made here, once per build, when the host asks for it.
-static vr_status contiguous_stream(BrickSet &b, Stream2 &s, const uint8_t **base)
+// Device address of brick `brick`'s contiguous preorder stream (the reference's tree.bits) of stream s.  After a fused
+// build the decoders read the block-gapped form; the reference's layout is in treeCompact, made at the end of build() or
+// here, on demand.  Its buffers are sized from the streams' real lengths: when a build's streams did not fit (the first
+// build of a set guesses; later ones may grow), the buffers are regrown to what is needed and the copy repeated.
+static vr_status contiguous_stream(BrickSet &b, Stream2 &s, int brick, const uint8_t **ptr)
 {
     if (!s.tree) return VR_ERR_STATE;
-    if (!b.gapped) { *base = s.tree; return VR_OK; }
-    if (!b.compactValid) {
-        const bool mr = b.variant == VR_VARIANT_MIDRANGE;
-        if (!b.mid.treeCompact) HIPCHK(hipMalloc(&b.mid.treeCompact, (size_t)b.B * b.treeCap));
-        if (mr && !b.rng.treeCompact) HIPCHK(hipMalloc(&b.rng.treeCompact, (size_t)b.B * b.treeCap));
+    if (!b.gapped) { *ptr = s.tree + (size_t)brick * b.treeCap; return VR_OK; }
+    const bool mr = b.variant == VR_VARIANT_MIDRANGE;
+    for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
-        const int rc = compact_launch(&b, (hipStream_t)b.lastStream);
-        HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
-        if (rc != 0) return VR_ERR_NO_DEVICE;
-        b.compactValid = true;
-        // (an emit overflow would have been flagged in the control blocks: re-read them)
-        HIPCHK(hipMemcpy(b.hostCtrl.data(), b.mid.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
-        b.hostCtrlValid = true;
+        if (!b.compactValid) {
+            const int rc = compact_launch(&b, (hipStream_t)b.lastStream);
+            if (rc != 0) return rc == -3 ? VR_ERR_OOM : VR_ERR_NO_DEVICE;
+            HIPCHK(hipStreamSynchronize((hipStream_t)b.lastStream));
+            b.hostBrickOff.clear();
+        }
+        if (b.hostBrickOff.size() != (size_t)b.B + 1) {
+            b.hostBrickOff.resize((size_t)b.B + 1);
+            HIPCHK(hipMemcpy(b.hostBrickOff.data(), b.brickOff, ((size_t)b.B + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            // (an emit overflow would have been flagged in the control blocks: re-read them)
+            HIPCHK(hipMemcpy(b.hostCtrl.data(), b.mid.ctrl, (size_t)b.B * sizeof(Ctrl), hipMemcpyDeviceToHost));
+            b.hostCtrlValid = true;
+        }
+        const int64_t total = (int64_t)b.hostBrickOff[(size_t)b.B];
+        if (total <= b.compactCap) break;
+        // did not fit: nothing was written.  Regrow (some headroom: the next timestep's streams differ) and repeat
+        hipFree(b.mid.treeCompact); b.mid.treeCompact = nullptr;
+        hipFree(b.rng.treeCompact); b.rng.treeCompact = nullptr;
+        const int64_t cap = total + total / 8 + 4096;
+        HIPCHK(hipMalloc(&b.mid.treeCompact, (size_t)cap));
+        if (mr) HIPCHK(hipMalloc(&b.rng.treeCompact, (size_t)cap));
+        b.compactCap = cap;
+        b.compactValid = false;
+        if (attempt == 1) return VR_ERR_STATE;
     }
-    *base = s.treeCompact;
+    *ptr = s.treeCompact + (size_t)b.hostBrickOff[(size_t)brick];
     return VR_OK;
 }
 
@@ -441,11 +467,11 @@ static vr_status get_tree_common(BrickSet &b, Stream2 &s, int brick, uint8_t *ds
     if (rc != VR_OK) return rc;
     int64_t bytes = ((int64_t)b.hostCtrl[brick].numActive + 3) / 4;
     if (!dst || cap < bytes) return VR_ERR_INVALID;
-    const uint8_t *base = nullptr;
-    rc = contiguous_stream(b, s, &base);
+    const uint8_t *src = nullptr;
+    rc = contiguous_stream(b, s, brick, &src);
     if (rc != VR_OK) return rc;
     if (b.hostCtrl[brick].emitOverflow) return VR_ERR_STATE;
-    HIPCHK(hipMemcpy(dst, base + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return VR_OK;
 }
 
@@ -506,11 +532,11 @@ vr_status vr_brickset_get_packed4(vr_brickset *h, int32_t brick, uint8_t *dst, i
     const int64_t bytes = (n + 3) / 4;
     std::vector<uint8_t> m((size_t)bytes), r((size_t)bytes);
     const uint8_t *baseM = nullptr, *baseR = nullptr;
-    rc = contiguous_stream(b, b.mid, &baseM);
-    if (rc == VR_OK) rc = contiguous_stream(b, b.rng, &baseR);
+    rc = contiguous_stream(b, b.mid, brick, &baseM);
+    if (rc == VR_OK) rc = contiguous_stream(b, b.rng, brick, &baseR);
     if (rc != VR_OK) return rc;
-    HIPCHK(hipMemcpy(m.data(), baseM + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(r.data(), baseR + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(m.data(), baseM, (size_t)bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r.data(), baseR, (size_t)bytes, hipMemcpyDeviceToHost));
     memset(dst, 0, (size_t)v);
     auto get = [](const std::vector<uint8_t> &a, int64_t i) { return (a[(size_t)(i >> 2)] >> ((i & 3) * 2)) & 3; };
     int64_t o = 0;
@@ -637,9 +663,9 @@ vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
     if (bytes == 0) return VR_ERR_STATE;
     std::vector<uint8_t> tree((size_t)bytes);
     const uint8_t *baseM = nullptr;
-    rc = contiguous_stream(b, b.mid, &baseM);
+    rc = contiguous_stream(b, b.mid, brick, &baseM);
     if (rc != VR_OK) return rc;
-    HIPCHK(hipMemcpy(tree.data(), baseM + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tree.data(), baseM, (size_t)bytes, hipMemcpyDeviceToHost));
     // MidRangeTree::save (M.cpp:753-785): same header, then distanceMap, distanceMap_range, tree, tree_range
     const bool mrFile = b.variant == VR_VARIANT_MIDRANGE;
     std::vector<uint8_t> treeR;
@@ -648,9 +674,9 @@ vr_status vr_brickset_save(vr_brickset *h, int32_t brick, const char *path)
         if (b.foreign && !b.foreignRange) return VR_ERR_STATE;
         treeR.resize((size_t)bytes);
         const uint8_t *baseR = nullptr;
-        rc = contiguous_stream(b, b.rng, &baseR);
+        rc = contiguous_stream(b, b.rng, brick, &baseR);
         if (rc != VR_OK) return rc;
-        HIPCHK(hipMemcpy(treeR.data(), baseR + (size_t)brick * b.treeCap, (size_t)bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(treeR.data(), baseR, (size_t)bytes, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&cr, b.rng.ctrl + brick, sizeof(Ctrl), hipMemcpyDeviceToHost));
     }
     FILE *f = fopen(path, "wb");

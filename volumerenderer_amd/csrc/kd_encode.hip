@@ -1444,6 +1444,8 @@ struct EmitArgs {
     int64_t nEmitBlk;
     uint8_t *tree, *treeR;
     int64_t treeCap;
+    const unsigned long long *brickOff;   // compact_launch: brick b's stream starts at tree + brickOff[b] (else at tree + b * treeCap)
+    int64_t compactCap;
     uint32_t *idxOff;
     uint8_t *idxVal;
     uint8_t *idxVal3;              // k_concat12: decoded scalars of the depth-(D-3) nodes (k_decode_quad)
@@ -1959,10 +1961,12 @@ k_emit_zero(EmitArgs a, int64_t nblk)
     const int brick = blockIdx.y;
     int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (blk >= nblk || a.ctrls[brick].constBrick) return;
+    if (a.brickOff && a.brickOff[gridDim.y] > (unsigned long long)a.compactCap) return;       // (did not fit: nothing is written)
     const unsigned long long g0 = a.blockOff64 ? a.blockOff64[(int64_t)brick * a.nEmitBlk + blk] : a.blockOff[(int64_t)brick * a.nEmitBlk + blk];
     uint32_t tot = a.blockTot[(int64_t)brick * a.nEmitBlk + blk];
-    uint32_t *W = (uint32_t *)(a.tree + (int64_t)brick * a.treeCap);
-    uint32_t *WR = a.treeR ? (uint32_t *)(a.treeR + (int64_t)brick * a.treeCap) : nullptr;
+    const int64_t base = a.brickOff ? (int64_t)a.brickOff[brick] : (int64_t)brick * a.treeCap;
+    uint32_t *W = (uint32_t *)(a.tree + base);
+    uint32_t *WR = a.treeR ? (uint32_t *)(a.treeR + base) : nullptr;
     if (tot == 0) {
         if (blk == 0 && a.ctrls[brick].numActive == 0) { W[0] = 0; if (WR) WR[0] = 0; }
         return;
@@ -1970,6 +1974,34 @@ k_emit_zero(EmitArgs a, int64_t nblk)
     W[g0 >> 4] = 0;
     W[(g0 + tot - 1) >> 4] = 0;
     if (WR) { WR[g0 >> 4] = 0; WR[(g0 + tot - 1) >> 4] = 0; }
+}
+
+// byte offset of every brick's contiguous stream in the compact buffers (16-byte aligned, one spare word each) and
+// their total; the streams of all bricks back to back take what they take, not B times the worst case
+__global__ void __launch_bounds__(1024)
+k_brick_offsets(const Ctrl *ctrls, int B, unsigned long long *brickOff, int64_t cap, int32_t *overflow)
+{
+    __shared__ unsigned long long part[16];
+    __shared__ unsigned long long carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + t;
+        unsigned long long bytes = 0;
+        if (b < B) bytes = ((((ctrls[b].numActive + 15ull) >> 4) + 1ull) * 4ull + 15ull) & ~15ull;
+        unsigned long long incl = bytes;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long n = __shfl_up(incl, o); if ((t & 63) >= o) incl += n; }
+        if ((t & 63) == 63) part[t >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (int i = 0; i < (t >> 6); ++i) before += part[i];
+        if (b < B) brickOff[b] = before + incl - bytes;
+        __syncthreads();
+        if (t == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) { brickOff[B] = carry; *overflow = carry > (unsigned long long)cap ? 1 : 0; }
 }
 
 #define EMIT_LDS_WORDS 256   // 4096 tokens >= 256*9 + 511 + 32 (+15 phase)
@@ -2369,57 +2401,152 @@ k_index12(EmitArgs a)
     *(uint2 *)(a.idxVal3 + io * 8) = make_uint2(lo3, hi3);
 }
 
-// The reference's layout on demand: block b contributes the upper spine its first rank owns (k_block_alive) and, if its
-// depth-(D-12) root is live, its string from the gapped buffer, at token offset blockOff[b] of the contiguous stream
-// (a.tree / a.treeR here = the destination).
+// The reference's contiguous layout (R.cpp:631-718 writes one array): block b contributes the upper spine its first rank
+// owns (k_block_alive) and, if its depth-(D-12) root is live, its string from the gapped buffer, at token offset
+// blockOff[b] of the brick's stream (a.tree / a.treeR = the destination, brick b at a.brickOff[b]).
+// A workgroup takes 16 consecutive blocks = one contiguous piece of the stream: their metadata in one batch of loads;
+// the short ones (two thirds of the bench volume's blocks are a spine and one token) by one lane each; the long ones
+// by all 256 threads, four destination words per thread and trip from five source words (one 16-byte and one 4-byte
+// load, funnel shifts, one 16-byte store).  A word two blocks share is merged in LDS and written once; only the
+// piece's very first and last word can belong to a neighbouring workgroup too: those were zeroed by k_emit_zero and
+// take atomicOr (two atomics per workgroup instead of two per block: the atomics were a third of this kernel).
+#define CC_BLOCKS 16
 template <bool RANGE>        // RANGE: MidRangeTree's second stream -- same offsets and shape, its own strings and spine
-__global__ void __launch_bounds__(64)
-k_concat12(EmitArgs a, const uint8_t *__restrict__ gap)       // one wave per block string
+__global__ void __launch_bounds__(256)
+k_concat12(EmitArgs a, const uint8_t *__restrict__ gap, int64_t nblk)
 {
+    __shared__ unsigned long long g0S[CC_BLOCKS], spineS[CC_BLOCKS];
+    __shared__ uint32_t totS[CC_BLOCKS], cntS[CC_BLOCKS];
+    __shared__ unsigned long long bwIdx[2 * CC_BLOCKS];     // boundary words: destination word index (~0: unused slot) ...
+    __shared__ uint32_t bwVal[2 * CC_BLOCKS];               // ... and this block's bits of it
     const int brick = blockIdx.y, t = threadIdx.x;
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
-    const uint32_t blk = blockIdx.x;
-    const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
-    const int bflags = a.blockAlive[bo];
-    const unsigned long long upSpine = RANGE ? a.blockSpineR[bo] : a.blockSpine[bo];
-    const unsigned long long g0 = a.blockOff64 ? a.blockOff64[bo] : (unsigned long long)a.blockOff[bo];
-    const uint32_t tot = a.blockTot[bo];
-    const int nsp = (int)(upSpine >> 56);
-    const unsigned long long spine = upSpine & 0x00FFFFFFFFFFFFFFull;
-    if (!(bflags & 1) || tot == 0) return;
-    // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch
-    // would be a bug; it must surface as a failed parity check, not as a memory fault)
-    if ((g0 + tot + 32ull) * 2ull > (unsigned long long)a.treeCap * 8ull) {
-        if (t == 0) atomicMax(&c.emitOverflow, 1);
-        return;
-    }
-    const uint32_t cnt = (bflags & 2) ? tot - (uint32_t)nsp : 0u;      // tokens of the block's own string
-    const int nws = (int)((cnt + 15u) >> 4);
-    const uint32_t phase = (uint32_t)(g0 & 15ull);
-    const uint32_t nwo = ((phase + tot - 1u) >> 4) + 1u;
-    uint32_t *G = (uint32_t *)((RANGE ? a.treeR : a.tree) + (int64_t)brick * a.treeCap) + (g0 >> 4);
-    const uint32_t *slot = (const uint32_t *)(gap + (int64_t)brick * a.treeCap) + (size_t)blk * PE_WORDS;
-    for (uint32_t i0 = 0; i0 < nwo; i0 += 256) {        // four words per lane and trip: eight loads in flight
-        uint32_t lo[4], hi[4];
-        int sbv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
-            const int so = 2 * (16 * (int)i - (int)phase) - 2 * nsp, sw = so >> 5;     // bit offset in the string (floor division)
-            sbv[u] = so & 31;
-            lo[u] = (cnt && i < nwo && sw >= 0 && sw < nws) ? slot[sw] : 0u;
-            hi[u] = (cnt && i < nwo && sw + 1 >= 0 && sw + 1 < nws) ? slot[sw + 1] : 0u;
+    if (a.brickOff && a.brickOff[gridDim.y] > (unsigned long long)a.compactCap) return;       // (did not fit: the host regrows and repeats)
+    const int64_t blk0 = (int64_t)blockIdx.x * CC_BLOCKS;
+    const int64_t base = a.brickOff ? (int64_t)a.brickOff[brick] : (int64_t)brick * a.treeCap;
+    uint32_t *G0 = (uint32_t *)((RANGE ? a.treeR : a.tree) + base);
+    const uint64_t capTok = a.brickOff ? ~0ull >> 2 : (uint64_t)a.treeCap * 4ull;            // tokens the brick's buffer holds
+    if (t < 2 * CC_BLOCKS) { bwIdx[t] = ~0ull; bwVal[t] = 0u; }
+    if (t < CC_BLOCKS) {
+        const int64_t blk = blk0 + t;
+        unsigned long long g0 = 0, sp = 0;
+        uint32_t tot = 0, cnt = 0;
+        if (blk < nblk) {
+            const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
+            const int bflags = a.blockAlive[bo];
+            sp = RANGE ? a.blockSpineR[bo] : a.blockSpine[bo];
+            g0 = a.blockOff64 ? a.blockOff64[bo] : (unsigned long long)a.blockOff[bo];
+            tot = (bflags & 1) ? a.blockTot[bo] : 0u;
+            cnt = (bflags & 2) && tot ? tot - (uint32_t)(sp >> 56) : 0u;      // tokens of the block's own string
+            // never write outside the brick's stream buffer, whatever the counts say (a count/emit mismatch would be a
+            // bug; it must surface as a failed parity check, not as a memory fault)
+            if (tot && g0 + tot + 32ull > capTok) { atomicMax(&c.emitOverflow, 1); tot = 0; cnt = 0; }
         }
+        g0S[t] = g0; spineS[t] = sp; totS[t] = tot; cntS[t] = cnt;
+    }
+    __syncthreads();
+    // ---- short blocks (spine + string of at most 32 tokens): one lane each
+    if (t < CC_BLOCKS && totS[t] != 0u && totS[t] <= 32u) {
+        const unsigned long long g0 = g0S[t];
+        const uint32_t tot = totS[t], cnt = cntS[t];
+        const int nsp = (int)(spineS[t] >> 56);
+        unsigned long long v = spineS[t] & 0x00FFFFFFFFFFFFFFull;
+        if (cnt) {
+            const uint32_t *slot = (const uint32_t *)(gap + (int64_t)brick * a.treeCap) + (size_t)(blk0 + t) * PE_WORDS;
+            unsigned long long sv = slot[0];
+            if (cnt > 16u) sv |= (unsigned long long)slot[1] << 32;
+            if (cnt < 32u) sv &= (1ull << (2 * cnt)) - 1ull;
+            v |= sv << (2 * nsp);
+        }
+        const uint32_t sh = (uint32_t)(g0 & 15ull) * 2u;
+        const uint64_t w0 = g0 >> 4, wl = (g0 + tot - 1) >> 4;       // first and last word (shared with the neighbours)
+        const uint32_t x0 = (uint32_t)(v << sh), x1 = (uint32_t)((v << sh) >> 32), x2 = sh ? (uint32_t)(v >> (64u - sh)) : 0u;
+        bwIdx[2 * t] = w0; bwVal[2 * t] = x0;
+        if (wl == w0 + 1) { bwIdx[2 * t + 1] = wl; bwVal[2 * t + 1] = x1; }
+        else if (wl == w0 + 2) { G0[w0 + 1] = x1; bwIdx[2 * t + 1] = wl; bwVal[2 * t + 1] = x2; }
+    }
+    // ---- long blocks: all threads, four destination words per thread and trip
+    for (int i = 0; i < CC_BLOCKS; ++i) {
+        const uint32_t tot = totS[i];
+        if (tot <= 32u) continue;
+        const unsigned long long g0 = g0S[i];
+        const uint32_t cnt = cntS[i];
+        const int nsp = (int)(spineS[i] >> 56);
+        const unsigned long long spine = spineS[i] & 0x00FFFFFFFFFFFFFFull;
+        const int nws = (int)((cnt + 15u) >> 4);
+        const uint32_t *slot = (const uint32_t *)(gap + (int64_t)brick * a.treeCap) + (size_t)(blk0 + i) * PE_WORDS;
+        const uint64_t w0 = g0 >> 4, wl = (g0 + tot - 1) >> 4;
+        const uint64_t wA = w0 & ~3ull;                                  // first destination word of chunk 0 (16-byte aligned)
+        const int nchunk = (int)((wl - wA) / 4 + 1);
+        // bit offset of word wA in the block's string (negative: in front of it)
+        const long long soA = 2ll * ((long long)(16ull * wA) - (long long)g0 - nsp);
+        for (int q = t; q < nchunk; q += 256) {
+            const uint64_t d0 = wA + 4ull * (uint64_t)q;                   // my four destination words d0 .. d0+3
+            const long long so = soA + 128ll * q;
+            const int sw = (int)(so >> 5);                                 // (floor division)
+            const uint32_t shf = (uint32_t)(so & 31ll);
+            uint32_t sv[5];
+            if (cnt && sw >= 0 && sw + 4 < nws) {                          // the common case: five words inside the string
+                struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
+                const U4 u = *(const U4 *)(slot + sw);
+                sv[0] = u.x; sv[1] = u.y; sv[2] = u.z; sv[3] = u.w; sv[4] = slot[sw + 4];
+            } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + (uint32_t)u * 64u + (uint32_t)t;
-            if (i >= nwo) continue;
-            const int bo2 = 2 * (16 * (int)i - (int)phase);            // bit offset of this word in spine ++ string
-            uint32_t v = sbv[u] ? (lo[u] >> sbv[u]) | (hi[u] << (32 - sbv[u])) : lo[u];
-            if (nsp) v |= bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
-            if (i == 0 || i == nwo - 1) { if (v) atomicOr(&G[i], v); }
-            else G[i] = v;
+                for (int k = 0; k < 5; ++k) sv[k] = (cnt && sw + k >= 0 && sw + k < nws) ? slot[sw + k] : 0u;
+            }
+            uint32_t o[4];
+            const int tok0 = (int)(so >> 1);                               // string token at bit 0 of word d0
+            const bool edge = tok0 < 0 || tok0 + 64 > (int)cnt;            // the chunk touches the string's start or end
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = __builtin_amdgcn_alignbit(sv[k + 1], sv[k], shf);
+                if (edge) {
+                    const int tokAt = tok0 + 16 * k;
+                    if (tokAt + 16 > (int)cnt) {        // the string's last word may carry stale bits behind the last token: cut them
+                        const int keep = (int)cnt - tokAt;
+                        o[k] = keep <= 0 ? 0u : (keep >= 16 ? o[k] : (o[k] & ((1u << (2 * keep)) - 1u)));
+                    }
+                    if (tokAt < 0 && nsp) {             // in front of the string: the spine's bits
+                        const long long bo2 = 2ll * ((long long)(16ull * (d0 + k)) - (long long)g0);
+                        o[k] |= bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
+                    }
+                }
+            }
+            if (d0 > w0 && d0 + 3 < wl) {
+                *(uint4 *)(G0 + d0) = make_uint4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t d = d0 + k;
+                    if (d < w0 || d > wl) continue;
+                    if (d == w0) { bwIdx[2 * i] = d; bwVal[2 * i] = o[k]; }
+                    else if (d == wl) { bwIdx[2 * i + 1] = d; bwVal[2 * i + 1] = o[k]; }
+                    else G0[d] = o[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the boundary words: slots are in stream order, so equal words are neighbours; the first slot of a word writes
+    // the OR of all of them
+    if (t < 2 * CC_BLOCKS) {
+        const unsigned long long w = bwIdx[t];
+        if (w != ~0ull) {
+            bool first = true;
+            uint32_t v = 0;
+            unsigned long long wFirst = ~0ull, wLast = 0;
+            for (int j = 0; j < 2 * CC_BLOCKS; ++j) {
+                const unsigned long long wj = bwIdx[j];
+                if (wj == ~0ull) continue;
+                if (wFirst == ~0ull) wFirst = wj;
+                wLast = wj;
+                if (wj == w) { v |= bwVal[j]; if (j < t) first = false; }
+            }
+            if (first) {
+                if (w == wFirst || w == wLast) { if (v) atomicOr(&G0[w], v); }
+                else G0[w] = v;
+            }
         }
     }
 }
@@ -2452,16 +2579,18 @@ k_emit_stats(EmitArgs a, int64_t nblk)
 // is "dead" with scalar v.  Identical to what the general path produces (tests compare both with
 // the oracle); it just skips ~all work for the constant regions of a volume.
 __global__ void __launch_bounds__(256)
-k_const_finish(int D, Ctrl *ctrls, uint8_t *tree, int64_t treeCap, uint32_t *idxOff, uint8_t *idxVal, int64_t nIdx)
+k_const_finish(int D, Ctrl *ctrls, uint8_t *tree, int64_t treeCap, uint32_t *idxOff, uint8_t *idxVal, int64_t nIdx,
+               const unsigned long long *brickOff = nullptr, int64_t compactCap = 0)
 {
     const int brick = blockIdx.y;
     Ctrl &c = ctrls[brick];
     if (!c.constBrick) return;
+    if (brickOff && brickOff[gridDim.y] > (unsigned long long)compactCap) return;
     const int v = c.constVal;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int d = 0; d <= D; ++d) c.distanceMap[d] = d == 0 ? (uint8_t)v : 0;
         c.numActive = v ? 3 : 1;
-        *(uint32_t *)(tree + (int64_t)brick * treeCap) = v ? 0x3Du : 0x03u;
+        *(uint32_t *)(tree + (brickOff ? (int64_t)brickOff[brick] : (int64_t)brick * treeCap)) = v ? 0x3Du : 0x03u;
         c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0; c.statL1 = 0; c.emitOverflow = 0;
     }
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2473,14 +2602,16 @@ k_const_finish(int D, Ctrl *ctrls, uint8_t *tree, int64_t treeCap, uint32_t *idx
 
 // The half-range stream of such a brick (MidRangeTree): every half range is 0, the root's distance 0 and code "keep",
 // the shape the mid stream's (M.cpp:864-865): [0][3][3], or [3] where the mid stream is [3]; distanceMap all zero.
-__global__ void k_const_finish_range(int D, Ctrl *ctrlsR, uint8_t *treeR, int64_t treeCap)
+__global__ void k_const_finish_range(int D, Ctrl *ctrlsR, uint8_t *treeR, int64_t treeCap, const unsigned long long *brickOff = nullptr,
+                                     int64_t compactCap = 0)
 {
     Ctrl &c = ctrlsR[blockIdx.x];
     if (threadIdx.x || !c.constBrick) return;
+    if (brickOff && brickOff[gridDim.x] > (unsigned long long)compactCap) return;
     const int v = c.constVal;             // the brick's VALUE (k_ctrl_init): decides the shape only
     for (int d = 0; d <= D; ++d) c.distanceMap[d] = 0;
     c.numActive = v ? 3 : 1;
-    *(uint32_t *)(treeR + (int64_t)blockIdx.x * treeCap) = v ? 0x3Cu : 0x03u;
+    *(uint32_t *)(treeR + (brickOff ? (int64_t)brickOff[blockIdx.x] : (int64_t)blockIdx.x * treeCap)) = v ? 0x3Cu : 0x03u;
     c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0; c.statL1 = 0; c.emitOverflow = 0;
 }
 
@@ -2573,26 +2704,45 @@ static void fill_emit_args(BrickSet *bs, EmitArgs &a)
     a.blockL1 = bs->blockL1;
     a.blockAlive = bs->blockAlive; a.blockVal = bs->blockVal; a.blockSpine = bs->blockSpine; a.blockSpineR = bs->blockSpineR;
     a.tree = bs->mid.tree; a.treeR = mr ? bs->rng.tree : nullptr; a.treeCap = bs->treeCap;
+    a.brickOff = nullptr; a.compactCap = 0;
     a.idxOff = bs->idxOff; a.idxVal = bs->idxVal; a.idxVal3 = bs->idxVal3; a.nIdx = bs->nIdx;
     a.chainLut = bs->chainLut;
 }
 
-// The reference's contiguous stream(s) of a fused build, into bs->mid.treeCompact (and rng.treeCompact): zero the words
-// two blocks share, then one wave per block copies spine + string to blockOff[b].  Runs when the host asks for bytes.
+// The reference's contiguous stream(s) of a fused build, into bs->mid.treeCompact (and rng.treeCompact): the bricks'
+// byte offsets (their streams back to back), the words two blocks share zeroed, then spine + string of every block to
+// its place.  At the end of build() (BrickSet::compactOnBuild) or when the host first asks for bytes.  The buffers are
+// sized from the streams' real lengths: the first build of a set guesses, a stream that does not fit raises
+// compactOverflow and writes nothing, and the host (capi.hip contiguous_stream) regrows the buffers and repeats.
 int compact_launch(BrickSet *bs, hipStream_t st)
 {
     const int D = bs->D, B = bs->B;
     const bool mr = bs->variant == 2;
+    if (!bs->brickOff && hipMalloc(&bs->brickOff, (size_t)(B + 1) * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (!bs->compactOverflow && hipMalloc(&bs->compactOverflow, sizeof(int32_t)) != hipSuccess) return -3;
+    if (bs->compactCap == 0) {
+        // first time: 5/8 byte per voxel (the bench volume takes 0.56; noise takes up to 2.3) -- a guess, corrected on demand
+        int64_t cap = (int64_t)B * bs->g.voxels / 8 * 5 + (int64_t)B * 64 + 4096;
+        const int64_t worst = (int64_t)B * bs->treeCap;
+        if (cap > worst) cap = worst;
+        if (hipMalloc(&bs->mid.treeCompact, (size_t)cap) != hipSuccess) return -3;
+        if (mr && hipMalloc(&bs->rng.treeCompact, (size_t)cap) != hipSuccess) { hipFree(bs->mid.treeCompact); bs->mid.treeCompact = nullptr; return -3; }
+        bs->compactCap = cap;
+    }
     EmitArgs a;
     fill_emit_args(bs, a);
     a.tree = bs->mid.treeCompact; a.treeR = mr ? bs->rng.treeCompact : nullptr;
+    a.brickOff = bs->brickOff; a.compactCap = bs->compactCap;
     const int64_t nblk = cdiv((int64_t)1 << D, 4096);
+    // constant bricks first: their token counts (closed form) are part of the offsets
+    hipLaunchKernelGGL(k_brick_offsets, dim3(1), dim3(1024), 0, st, bs->mid.ctrl, B, bs->brickOff, bs->compactCap, bs->compactOverflow);
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
-    hipLaunchKernelGGL(k_concat12<false>, dim3((unsigned)nblk, B), dim3(64), 0, st, a, bs->mid.tree);
-    if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3((unsigned)nblk, B), dim3(64), 0, st, a, bs->rng.tree);
+    hipLaunchKernelGGL(k_concat12<false>, dim3(cdiv(nblk, CC_BLOCKS), B), dim3(256), 0, st, a, bs->mid.tree, nblk);
+    if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3(cdiv(nblk, CC_BLOCKS), B), dim3(256), 0, st, a, bs->rng.tree, nblk);
     hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.treeCompact,
-                       bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
-    if (mr) hipLaunchKernelGGL(k_const_finish_range, dim3(B), dim3(64), 0, st, D, bs->rng.ctrl, bs->rng.treeCompact, bs->treeCap);
+                       bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx, bs->brickOff, bs->compactCap);
+    if (mr) hipLaunchKernelGGL(k_const_finish_range, dim3(B), dim3(64), 0, st, D, bs->rng.ctrl, bs->rng.treeCompact, bs->treeCap, bs->brickOff, bs->compactCap);
+    bs->compactValid = true;
     return launch_status("compact");
 }
 
@@ -2801,6 +2951,12 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.tree,
                        bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx);
     if (mr) hipLaunchKernelGGL(k_const_finish_range, dim3(B), dim3(64), 0, st, D, bs->rng.ctrl, bs->rng.tree, bs->treeCap);
+    // the reference's build() ends with the contiguous stream (tree.swap(preorderTree), R.cpp:714-718): so does this one,
+    // unless the caller turned it off (vr_brickset_set_compaction): the decoders read the block strings where they are
+    if (fused && bs->compactOnBuild) {
+        const int rc = compact_launch(bs, st);
+        if (rc != 0) return rc;
+    }
     hipEventRecord(bs->ev[4], st);
     dbg_sync(st, "emit_write");
     return launch_status("encode");
