@@ -246,6 +246,42 @@ vr_status vr_composite_slabs(const float *partials_dev, int32_t num_slabs, int64
                              int32_t axis, const vr_camera *cam, const vr_render_params *params, float *rgba_dev,
                              void *stream);
 
+/* ---- sort-last compositing across the GPUs of a node (new: the reference is single-GPU) ----------------
+ * One process per GPU.  Rank r ray-marches slab r of the volume along `axis` into a VR_RENDER_PARTIAL image
+ * (width * height * 4 floats); vr_compositor_composite moves tile t (a block of rows) of every rank's image to rank t
+ * in ONE grouped RCCL call (ncclSend / ncclRecv over xGMI), combines the `world` partials of its tile per pixel in that
+ * pixel's view order (vr_composite_slabs) and gathers the finished RGBA tiles on rank 0 (rgba_dev: width * height * 4
+ * floats there, ignored elsewhere).  All of it is queued on `stream`.  The communicator is either the library's own,
+ * created from an ncclUniqueId the ranks share (vr_rccl_unique_id on one rank, passed on by whatever the host uses
+ * to talk between its processes), or the caller's ncclComm_t.  RCCL is bound at run time: world == 1 needs none, and
+ * VR_ERR_UNSUPPORTED comes back where it cannot be found.  The alpha > 0.99 early exit of raycaster.frag:76 cannot be
+ * honoured across slabs (bounded difference, <= 0.017 per channel). */
+typedef struct vr_compositor vr_compositor;
+vr_status vr_rccl_unique_id(uint8_t id[128]);
+vr_status vr_compositor_create(vr_compositor **out, const uint8_t id[128], int32_t rank, int32_t world,
+                               int32_t width, int32_t height);
+vr_status vr_compositor_create_from_comm(vr_compositor **out, void *nccl_comm, int32_t rank, int32_t world,
+                                         int32_t width, int32_t height);
+vr_status vr_compositor_composite(vr_compositor *c, const float *partial_dev, int32_t axis, const vr_camera *cam,
+                                  const vr_render_params *params, float *rgba_dev, void *stream);
+vr_status vr_compositor_destroy(vr_compositor *c);
+
+/* ---- streams, events, pinned host memory (what include/vrhip/TimestepStreamer.hpp overlaps the stages of a timestep
+ * stream with: main.cpp:242-290 runs them one after another).  Streams and events travel as void*. */
+vr_status vr_stream_create(void **stream);
+vr_status vr_stream_destroy(void *stream);
+vr_status vr_stream_synchronize(void *stream);
+vr_status vr_stream_wait_event(void *stream, void *event);
+vr_status vr_event_create(void **event);
+vr_status vr_event_destroy(void *event);
+vr_status vr_event_record(void *event, void *stream);
+vr_status vr_event_synchronize(void *event);
+vr_status vr_event_elapsed_ms(void *start_event, void *end_event, float *ms);
+vr_status vr_malloc_host(void **host, int64_t bytes);
+vr_status vr_free_host(void *host);
+vr_status vr_upload_async(void *dst_dev, const void *src_host, int64_t bytes, void *stream);
+vr_status vr_download_async(void *dst_host, const void *src_dev, int64_t bytes, void *stream);
+
 /* ---- instrumentation (the reference's DebugTimer phases, R.cpp:47-113) ----------
  * Milliseconds of the last build / decode measured with hipEvents on the call's stream:
  * phases[0..4] = BUILD(pyramid), COMPRESS, PRUNE, CONVERT, DECODE. */

@@ -191,6 +191,39 @@ def test_composite_slabs_kernel_matches_oracle(vr, oracle):
     assert np.abs(tile - got[lo:hi]).max() <= 1e-6
 
 
+def test_c_abi_compositor_single_rank_and_rccl_binding(vr, oracle):
+    """vr_compositor_* (the C ABI a C++ host composites with): a one-rank compositor needs no communicator and must equal
+    the colour transfer of the partial image; the RCCL binding (dlopen at run time) must hand out an ncclUniqueId on a
+    box that has RCCL; composite_sort_last without a process group takes the same path."""
+    import ctypes as C
+    import torch
+    from volumerenderer_amd import _lib
+    from volumerenderer_amd import distributed as D
+    L = _lib.lib()
+    vol = oracle.gen_sphere(32, 3)
+    w, h = 96, 64
+    cg, co = _cams(vr, oracle, (0.3, 0.2, -0.9), (-0.2, -0.1, 1.0))
+    P = vr.default_params(w, h, (32, 32, 32), 2)
+    part = vr.raycast(vol.copy(), (32, 32, 32), cg, P)
+    hnd = C.c_void_p()
+    assert L.vr_compositor_create(C.byref(hnd), None, 0, 1, w, h) == 0
+    out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    full = vr.default_params(w, h, (32, 32, 32), 0)
+    assert L.vr_compositor_composite(hnd, C.c_void_p(part.data_ptr()), 2, C.byref(cg), C.byref(full), C.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    want = vr.composite_finish(part).cpu().numpy().reshape(h, w, 4)
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-6
+    bad = vr.default_params(w + 1, h, (32, 32, 32), 0)
+    assert L.vr_compositor_composite(hnd, C.c_void_p(part.data_ptr()), 2, C.byref(cg), C.byref(bad), C.c_void_p(out.data_ptr()), None) == -1
+    assert L.vr_compositor_destroy(hnd) == 0
+    frame = D.composite_sort_last(part, cg, full, axis=2)
+    assert np.abs(frame.cpu().numpy() - want).max() <= 1e-6
+    uid = (C.c_uint8 * 128)()
+    assert L.vr_rccl_unique_id(uid) == 0 and any(uid)         # RCCL found and bound (the image has it)
+    assert L.vr_compositor_create(C.byref(hnd), None, 0, 2, w, h) == -1      # more than one rank needs the shared id
+    assert L.vr_compositor_create(C.byref(hnd), uid, 2, 2, w, h) == -1       # rank out of range
+
+
 def test_config3_isosurface_of_brick_grid(vr, oracle):
     """BASELINE config 3: 2x2x2 bricks assembled into one volume, iso-surface shader at several iso values."""
     n = 32

@@ -5,12 +5,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvrhip.so")
-SOURCES = ["kd_encode.hip", "kd_decode.hip", "raymarch.hip", "capi.hip"]
+SOURCES = ["kd_encode.hip", "kd_decode.hip", "raymarch.hip", "capi.hip", "compositor.hip"]
 HEADERS = ["kd_common.h", "brickset.h", os.path.join("..", "..", "include", "vrhip.h")]
 # -ffp-contract=off: the gradient-descent control kernel and the ray marcher must round
 # exactly like the reference's scalar code (no FMA contraction).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
 # experiments: extra -D switches for tuning runs (part of the staleness hash, so a change rebuilds)
 FLAGS += os.environ.get("VRHIP_EXTRA_HIPCC_FLAGS", "").split()
 

@@ -80,6 +80,24 @@ SIGNATURES = {
     "vr_composite_over": (_I32, [_P, _P, _I64, _P]),
     "vr_composite_finish": (_I32, [_P, _P, _I64, _P]),
     "vr_composite_slabs": (_I32, [_P, _I32, _I64, _I64, _I32, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
+    "vr_rccl_unique_id": (_I32, [_P]),
+    "vr_compositor_create": (_I32, [C.POINTER(_P), _P, _I32, _I32, _I32, _I32]),
+    "vr_compositor_create_from_comm": (_I32, [C.POINTER(_P), _P, _I32, _I32, _I32, _I32]),
+    "vr_compositor_composite": (_I32, [_P, _P, _I32, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P]),
+    "vr_compositor_destroy": (_I32, [_P]),
+    "vr_stream_create": (_I32, [C.POINTER(_P)]),
+    "vr_stream_destroy": (_I32, [_P]),
+    "vr_stream_synchronize": (_I32, [_P]),
+    "vr_stream_wait_event": (_I32, [_P, _P]),
+    "vr_event_create": (_I32, [C.POINTER(_P)]),
+    "vr_event_destroy": (_I32, [_P]),
+    "vr_event_record": (_I32, [_P, _P]),
+    "vr_event_synchronize": (_I32, [_P]),
+    "vr_event_elapsed_ms": (_I32, [_P, _P, C.POINTER(C.c_float)]),
+    "vr_malloc_host": (_I32, [C.POINTER(_P), _I64]),
+    "vr_free_host": (_I32, [_P]),
+    "vr_upload_async": (_I32, [_P, _P, _I64, _P]),
+    "vr_download_async": (_I32, [_P, _P, _I64, _P]),
     "vr_brickset_last_timings": (_I32, [_P, C.POINTER(C.c_float)]),
     "vr_brickset_set_concurrency": (_I32, [_P, C.c_int32]),
     "vr_brickset_set_switch": (_I32, [_P, C.c_char_p, C.c_int32]),

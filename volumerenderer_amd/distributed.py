@@ -57,12 +57,54 @@ def _gpu_combine(parts, first_pixel, axis, cam, params):
     return out
 
 
-def composite_sort_last(partial, cam, params, axis=2, group=None, combine=None):
+_compositors = {}
+
+
+def _compositor(group, world, rank, W, H):
+    """The C-ABI compositor of (group, frame size): its RCCL communicator is created once from an ncclUniqueId that
+    rank 0 asks the library for and the process group passes on."""
+    key = (id(group), world, rank, W, H)
+    h = _compositors.get(key)
+    if h is None:
+        from . import _lib
+        from ._lib import check
+        L = _lib.lib()
+        uid = (C.c_uint8 * 128)()
+        if world > 1:
+            box = [None]
+            if rank == 0:
+                check(L.vr_rccl_unique_id(uid), "vr_rccl_unique_id")
+                box[0] = bytes(uid)
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        check(L.vr_compositor_create(C.byref(h), uid, rank, world, W, H), "vr_compositor_create")
+        _compositors[key] = h
+    return h
+
+
+def composite_sort_last(partial, cam, params, axis=2, group=None, combine=None, out=None):
     """partial: this rank's (c, tau, covered, 0) image [H][W][4] float32 (rank r holds slab r along
-    `axis`).  Returns the finished RGBA frame [H][W][4] on rank 0 (None elsewhere)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    `axis`).  Returns the finished RGBA frame [H][W][4] on rank 0 (None elsewhere).
+
+    Device tensors take the C-ABI compositor (vr_compositor_composite: grouped RCCL send/recv, k_composite_slabs,
+    gather -- what a C++ host calls).  With an injected `combine` (the CPU tests: gloo, the oracle's combine) the same
+    exchange runs over torch.distributed point-to-point operations."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
     H, W = partial.shape[0], partial.shape[1]
+    if combine is None and partial.is_cuda:
+        from . import _lib
+        from .codec import _stream_ptr
+        from ._lib import check
+        h = _compositor(group, world, rank, W, H)
+        frame = None
+        if rank == 0:
+            frame = out if out is not None else torch.empty((H, W, 4), dtype=torch.float32, device=partial.device)
+        check(_lib.lib().vr_compositor_composite(h, C.c_void_p(partial.data_ptr()), int(axis), C.byref(cam), C.byref(params),
+                                                 C.c_void_p(frame.data_ptr()) if rank == 0 else None, _stream_ptr()),
+              "vr_compositor_composite")
+        return frame
     combine = combine or _gpu_combine
     rows = tile_rows(H, world)
     if world == 1:
