@@ -8,8 +8,10 @@ Workload (BASELINE.json metric): one 2048x2048x1920 uint8 volume = the reference
 grid of 256x256x128 bricks (main.cpp:78-79), one kd-tree per brick, all 960 trees built and
 decoded by one batched launch sequence.  A "step" = build() + levelCut() of the whole
 volume (+ one 1080p ray-cast frame of the decoded volume, timed separately).
-N > 1: one rank per GPU over RCCL; bricks / timesteps shard with no data-path collective --
-every rank encodes+decodes its own timestep of the volume (weak scaling).  Launched either by
+N > 1: one rank per GPU over RCCL; the codec shards with no data-path collective.  Default = BASELINE config 4
+(--scaling strong): ONE volume, its 960 bricks dealt to the ranks by slabs of the brick grid, value = the volume's
+voxels / the slowest rank's time; then every rank ray-marches its slab and the frame is composited sort-last over RCCL
+(vr_compositor_composite) and compared with the one-GPU frame.  --scaling weak: one volume (timestep) per rank.  Launched either by
 torch.distributed.run (RANK / WORLD_SIZE in the environment) or plainly as `python bench.py
 --gpus N`: the parent then starts the N ranks itself, before it touches the GPU, and relays
 rank 0's JSON line.
@@ -138,9 +140,22 @@ def dry_run(args, rank, world):
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the strong-scaling partition: every brick of the volume on exactly one rank
+    from volumerenderer_amd import distributed as D
+    gdims, bdims = tuple(args.volume), tuple(args.dims)
+    grid = tuple(gdims[a] // bdims[a] for a in range(3))
+    ids, slab = D.shard_bricks_by_slab(grid, rank, world, axis=1)
+    per_rank = [ids]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, ids)
     if rank == 0:
+        flat = sorted(sum(per_rank, []))
         print(json.dumps({"metric": "Mvoxels/s kd-tree compress+decode", "value": None, "unit": "Mvoxels/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "scaling": args.scaling if world > 1 else "weak",
+                          "bricks_per_rank": [len(x) for x in per_rank],
+                          "partition_ok": flat == list(range(grid[0] * grid[1] * grid[2])),
                           "max_rank_seconds": round(dt, 4)}))
     if world > 1:
         dist.destroy_process_group()
@@ -318,9 +333,12 @@ def main():
                     help="vr_brickset_set_concurrency for the strictly serial pass (library default 2; 1 for clean "
                          "per-kernel profiles).  The pipelined sets always use 1")
     ap.add_argument("--no-extra-timing", action="store_true", help="skip the second timed pass (value_no_compact)")
-    ap.add_argument("--composite", action="store_true",
-                    help="N > 1 only: also time a sort-last composited 1080p frame over RCCL (off by default: a "
-                         "collective that fails on one rank must never hang the headline measurement)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong (default, BASELINE config 4) = ONE volume, its bricks dealt to the ranks by slabs of the "
+                         "brick grid along y, value = the volume's voxels / the slowest rank's time; weak = one volume per rank")
+    ap.add_argument("--no-composite", action="store_true",
+                    help="N > 1: skip the sort-last composited 1080p frames over RCCL (they run by default, after the timed "
+                         "region, under the process group's timeout: a collective that fails ends the run non-zero)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -346,10 +364,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     if world > 1:
+        import datetime
+        # a collective that cannot complete ends the run (non-zero exit) after this long instead of hanging it
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("VRHIP_BENCH_PG_TIMEOUT", "300")))
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
 
     import volumerenderer_amd as vr
 
@@ -357,7 +378,21 @@ def main():
     gdims = tuple(args.volume)
     V = bdims[0] * bdims[1] * bdims[2]
     grid = tuple(gdims[a] // bdims[a] for a in range(3))
-    if args.kind in ("rm_volume",):
+    strong = world > 1 and args.scaling == "strong" and args.kind == "rm_volume" and not args.bricks
+    my_ids, my_slab = None, None
+    B_total = None
+    if strong:
+        # BASELINE config 4: ONE volume (the same seed on every rank), its bricks dealt to the ranks by slabs of the brick
+        # grid along y (8 brick rows: even shares for 2, 4 and 8 ranks; fillVolumeBrickMap order, main.cpp:599-619).  No
+        # data-path collective: every rank builds and decodes its own bricks.
+        from volumerenderer_amd import distributed as D
+        vox_all = make_volume_gpu(torch, gdims, bdims, seed=12345, kind=args.kind)
+        B_total = vox_all.shape[0]
+        my_ids, my_slab = D.shard_bricks_by_slab(grid, rank, world, axis=1)
+        vox4 = vox_all[torch.tensor(my_ids, device="cuda")].contiguous()
+        del vox_all
+        torch.cuda.empty_cache()
+    elif args.kind in ("rm_volume",):
         vox4 = make_volume_gpu(torch, gdims, bdims, seed=12345 + 1000 * rank, kind=args.kind)  # rank = timestep
         if args.bricks:
             # keep the bricks around the interface first (they are the expensive ones)
@@ -432,7 +467,7 @@ def main():
         tt = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    total_vox = float(V) * B * world * args.steps
+    total_vox = float(V) * (B_total if strong else B * world) * args.steps
     value = total_vox / dt / 1e6
     # the same steps without the contiguous copy of the compressed stream at the end of build() (vr_brickset_set_compaction:
     # a pipeline that only decodes on the device may leave it to the first get_tree / save): reported beside `value`, never as it
@@ -491,7 +526,7 @@ def main():
     try:
         pm = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
         if args.kind == "rm_volume" and not args.bricks and gdims == (2048, 2048, 1920) and bdims == (256, 256, 128) \
-                and args.tolerance == 1 and args.max_epochs == 2:
+                and args.tolerance == 1 and args.max_epochs == 2 and not strong:
             traffic = pm["decode_traffic_bytes_per_launch"]
     except Exception:
         pass
@@ -516,11 +551,12 @@ def main():
 
     res = {"metric": "Mvoxels/s kd-tree compress+decode", "value": round(value, 2), "unit": "Mvoxels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": "%dx%dx%d uint8 volume per GPU as %d bricks of %dx%dx%d (%s), tolerance %d, "
-                      "maxEpochs %d, VolumeKdtree build + levelCut" % (gdims[0], gdims[1], gdims[2], B, bdims[0],
-                                                                         bdims[1], bdims[2], args.kind, args.tolerance,
-                                                                         args.max_epochs),
+           "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": ("ONE %dx%dx%d uint8 volume, its %d bricks of %dx%dx%d dealt to %d ranks by slabs of the brick grid "
+                                   "along y (%d bricks on rank 0), " % (gdims[0], gdims[1], gdims[2], B_total, bdims[0], bdims[1], bdims[2], world, B)
+                                   if strong else
+                                   "%dx%dx%d uint8 volume per GPU as %d bricks of %dx%dx%d, " % (gdims[0], gdims[1], gdims[2], B, bdims[0], bdims[1], bdims[2]))
+                                  + "%s, tolerance %d, maxEpochs %d, VolumeKdtree build + levelCut" % (args.kind, args.tolerance, args.max_epochs),
                       "pipeline": ("%d bricksets in flight, each on its own stream: build + levelCut of step k run "
                                    "beside those of the following steps" % NS if NS >= 2 else "serial"),
                       "level_loop_streams": {"pipelined": 1 if NS >= 2 else args.level_loop_streams, "serial": args.level_loop_streams},
@@ -531,6 +567,7 @@ def main():
            "encode_ms": round(sum(enc_ms) / len(enc_ms), 3), "decode_ms": round(dec_avg_s * 1e3, 3),
            "phases_ms": {k: round(v, 3) for k, v in phases.items()},
            "value_no_compact": round(value_nc, 2) if value_nc else None,
+           "backend": (dist.get_backend() if world > 1 else None), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
            "roofline": roofline, "roofline_encode": roofline_encode}
 
     if not args.no_render and not args.bricks and rank == 0:
@@ -570,41 +607,92 @@ def main():
             vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_ISOSURFACE, 40.0 / 255.0), sgrid, 8))
         del vol, sgrid
 
-    if world > 1 and args.composite and not args.bricks:
-        try:
-            # sort-last frame over RCCL: rank r ray-marches z-slab r of its volume (plus one halo layer) into a
-            # partial (c, tau) image; direct-send exchange + per-pixel ordered composite (distributed.py)
-            from volumerenderer_amd import distributed as D
+    if world > 1 and not args.no_composite and not args.bricks and args.kind == "rm_volume":
+        # sort-last frames over RCCL (the path's one real exchange): rank r ray-marches ITS slab of the decoded volume
+        # (strong: the y-slab of the bricks it decoded, plus one halo plane from each neighbour; weak: z-slab r of its own
+        # volume) into a partial (c, tau) image; vr_compositor_composite: direct-send exchange (grouped ncclSend / ncclRecv),
+        # per-pixel ordered combine, gather on rank 0.  A failure here ends the run non-zero (no retry, no re-exec): the
+        # process group's timeout turns a collective that cannot complete into an error.
+        from volumerenderer_amd import distributed as D
+        ax = 1 if strong else 2
+        if strong:
+            lo_b, hi_b = my_slab
+            ylo, yhi = lo_b * bdims[1], hi_b * bdims[1]
+            ijk = np.array([[b % grid[0], (b // grid[0]) % grid[1] - lo_b, b // (grid[0] * grid[1])] for b in my_ids], np.int64)
+            slab = vr.assemble_bricks(out, bdims, ijk, (grid[0], hi_b - lo_b, grid[2])).reshape(gdims[2], yhi - ylo, gdims[0])
+            # halo planes: my first plane to the rank below, my last one to the rank above
+            lo_halo = torch.empty((gdims[2], 1, gdims[0]), dtype=torch.uint8, device="cuda") if rank > 0 else None
+            hi_halo = torch.empty((gdims[2], 1, gdims[0]), dtype=torch.uint8, device="cuda") if rank < world - 1 else None
+            first, last = slab[:, :1].contiguous(), slab[:, -1:].contiguous()
+            ops = []
+            if rank > 0:
+                ops += [dist.P2POp(dist.isend, first, rank - 1), dist.P2POp(dist.irecv, lo_halo, rank - 1)]
+            if rank < world - 1:
+                ops += [dist.P2POp(dist.isend, last, rank + 1), dist.P2POp(dist.irecv, hi_halo, rank + 1)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            slab = torch.cat([t_ for t_ in (lo_halo, slab, hi_halo) if t_ is not None], dim=1).contiguous()
+            a0 = ylo - (1 if rank > 0 else 0)
+            sub_dims = (gdims[0], slab.shape[1], gdims[2])
+            lo_f, hi_f, ext = ylo, yhi, gdims[1]
+        else:
             vol = vr.assemble_bricks(out, bdims, np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])]
                                                             for b in range(B)], np.int64), grid)
             zlo, zhi = D.shard_range(gdims[2], rank, world)
             a0, a1 = max(0, zlo - 1), min(gdims[2], zhi + 1)
             slab = vol.reshape(gdims[2], gdims[1], gdims[0])[a0:a1].contiguous()
             del vol
-            cam = vr.default_camera()
-            P = vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_PARTIAL)
-            P.box_min[:] = (0.0, 0.0, zlo / gdims[2])
-            P.box_max[:] = (1.0, 1.0, zhi / gdims[2] if rank < world - 1 else 2.0)
-            P.global_dims[:] = gdims
-            P.vol_origin[:] = (0, 0, a0)
-            part = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
-            frames = 36
-            for warm in (True, False):
-                torch.cuda.synchronize()
-                dist.barrier()
-                r0 = time.perf_counter()
-                for f in range(frames):
-                    th = math.radians(f * 10.0)
-                    cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
-                    cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
-                    vr.raycast(slab.reshape(-1), (gdims[0], gdims[1], a1 - a0), cam, P, part)
-                    D.composite_sort_last(part, cam, P, axis=2)
-                torch.cuda.synchronize()
-                dist.barrier()
-                cfps = frames / (time.perf_counter() - r0)
-            res["composited_1080p_fps"] = round(cfps, 1)
-        except Exception as ex:   # the composited frame is an extra: never let it take the headline metric down
-            res["composited_1080p_error"] = repr(ex)[:200]
+            sub_dims = (gdims[0], gdims[1], a1 - a0)
+            lo_f, hi_f, ext = zlo, zhi, gdims[2]
+        cam = vr.default_camera()
+        P = vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_PARTIAL)
+        bmin, bmax, org = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 0, 0]
+        bmin[ax] = lo_f / ext
+        bmax[ax] = hi_f / ext if rank < world - 1 else 2.0
+        org[ax] = a0
+        P.box_min[:] = tuple(bmin); P.box_max[:] = tuple(bmax)
+        P.global_dims[:] = gdims
+        P.vol_origin[:] = tuple(org)
+        part = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+        frame = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        frames = 36
+        for warm in (True, False):
+            torch.cuda.synchronize()
+            dist.barrier()
+            r0 = time.perf_counter()
+            for f in range(frames):
+                th = math.radians(f * 10.0)
+                cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
+                cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
+                vr.raycast(slab.reshape(-1), sub_dims, cam, P, part)
+                D.composite_sort_last(part, cam, P, axis=ax, out=frame)
+            torch.cuda.synchronize()
+            dist.barrier()
+            cfps = frames / (time.perf_counter() - r0)
+        res["composited_1080p_fps"] = round(cfps, 1)
+        res["composite"] = {"axis": "xyz"[ax], "slab_voxels_rank0": [int(v) for v in sub_dims], "exchange": "vr_compositor_composite (C ABI): grouped "
+                            "ncclSend/ncclRecv direct send, k_composite_slabs, gather on rank 0"}
+        if strong and rank == 0:
+            # the same frame from one GPU: rank 0 decodes the whole volume once more (outside every timed region) and
+            # marches it without the early exit the slabs cannot honour (raycaster.frag:76)
+            del slab
+            sets, bs = None, None
+            torch.cuda.empty_cache()
+            try:
+                vox_all = make_volume_gpu(torch, gdims, bdims, seed=12345, kind=args.kind)
+                full_set = vr.BrickSet(B_total, bdims, args.tolerance, args.max_epochs)
+                full_set.set_compaction(False)
+                dec_all = full_set.build(vox_all.reshape(-1)).decode()
+                vol = vr.assemble_bricks(dec_all, bdims, np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])]
+                                                                    for b in range(B_total)], np.int64), grid)
+                Pf = vr.default_params(1920, 1080, (256, 256, 128))
+                Pf.no_early_exit = 1
+                ref = vr.raycast(vol, gdims, cam, Pf)               # the last camera of the orbit: `frame` holds that composite
+                res["composite_max_abs_diff"] = round(float((ref - frame).abs().max().item()), 6)
+                del vox_all, full_set, dec_all, vol, ref
+            except Exception as ex:
+                res["composite_max_abs_diff"] = None
+                res["composite_reference_error"] = repr(ex)[:200]
 
     if rank == 0 and world == 1 and not args.no_stream and not args.bricks and args.kind == "rm_volume":
         del sets, bs

@@ -24,6 +24,8 @@ def test_bench_prints_one_contract_line(pipeline):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
     assert j["unit"] == "Mvoxels/s" and j["dtype"] == "u8" and j["vs_baseline"] is None and j["scaling"] == "weak"
+    assert j["value_no_compact"] is None or j["value_no_compact"] > 0
+    assert j["roofline_encode"]["bound"] == "hbm" and j["roofline_encode"]["achieved"] > 0
     assert j["value"] > 0 and "workload" in j["config"]
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
@@ -47,6 +49,19 @@ def test_gpus_flag_starts_that_many_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["dry_run"] is True
     assert j["max_rank_seconds"] >= 0.02          # the slower rank's time (MAX over ranks)
+    # N > 1 defaults to BASELINE config 4: ONE volume, every one of its 960 bricks on exactly one rank
+    assert j["scaling"] == "strong" and j["partition_ok"] is True and j["bricks_per_rank"] == [480, 480]
+
+
+@pytest.mark.parametrize("n", [3, 4])
+def test_strong_scaling_partition_other_rank_counts(n):
+    env = dict(os.environ, VRHIP_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["partition_ok"] is True and sum(j["bricks_per_rank"]) == 960 and len(j["bricks_per_rank"]) == n
 
 
 def test_gpus_flag_must_match_world_size():
