@@ -309,6 +309,71 @@ def config5_leg(torch, vr, vox4, gdims, bdims, grid, args, timesteps=4, frames_p
             "midrange_build_plus_decode_ms": round(mr_ms, 2), "midrange_Mvoxels_per_s": round(B * V / mr_ms / 1e3, 1)}
 
 
+def general_extents_leg(torch, vr):
+    """The reference program's own volume (main.cpp:242-251): 384 bricks of 256x256x64 assembled into 2048x2048x768 and ONE
+    31-level VolumeKdtree over it (table-driven geometry, 64-bit token offsets): build + levelCut, milliseconds."""
+    gdims, bdims = (2048, 2048, 768), (256, 256, 64)
+    grid = tuple(gdims[k] // bdims[k] for k in range(3))
+    vox4 = make_volume_gpu(torch, gdims, bdims, seed=777)
+    B = vox4.shape[0]
+    ijk = np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])] for b in range(B)], np.int64)
+    vol = vr.assemble_bricks(vox4.reshape(-1), bdims, ijk, grid)
+    del vox4
+    t = vr.BrickSet(1, gdims, 1, 2)
+    out = torch.empty_like(vol)
+    best = None
+    for _ in range(2):
+        t.build(vol); t.decode(out)
+        torch.cuda.synchronize()
+        tm = t.last_timings()
+        ms = (tm["BUILD"] + tm["COMPRESS"] + tm["PRUNE"] + tm["CONVERT"], tm["DECODE"])
+        best = ms if best is None or sum(ms) < sum(best) else best
+    inf = t.info(0)
+    return {"volume": list(gdims), "orig_tree_depth": inf["orig_tree_depth"], "num_active_nodes": inf["num_active_nodes"],
+            "build_ms": round(best[0], 2), "levelcut_ms": round(best[1], 2),
+            "Mvoxels_per_s": round(gdims[0] * gdims[1] * gdims[2] / (best[0] + best[1]) / 1e3, 1)}
+
+
+def disk_stage_leg(torch, vr, vox4, gdims, bdims, grid, args, timesteps=2):
+    """config 5's disk stage at full size: `timesteps` x 960 raw brick files (VolumeReader<T>::LoadVolumeFromBinaryFile's
+    format: X*Y*Z bytes each) on local disk -> pinned host memory (reader thread) -> device -> build -> levelCut -> one
+    1080p frame; the time from the first file read to the first frame, and the whole run."""
+    import shutil
+    import tempfile
+    from volumerenderer_amd.pipeline import BrickFileSource, TimestepStreamer
+    B = vox4.shape[0]
+    d = tempfile.mkdtemp(prefix="vrhip_bricks_")
+    try:
+        host = vox4.cpu().numpy()
+        for t in range(timesteps):
+            for b in range(B):
+                host[(b + 7 * t) % B].tofile(os.path.join(d, "d_%d_%d" % (270 + t, b)))      # (timestep t: the bricks rotated)
+        del host
+        src = BrickFileSource(lambda b, t: os.path.join(d, "d_%d_%d" % (t, b)), B, bdims, [270 + t for t in range(timesteps)])
+        st = TimestepStreamer(B, bdims, args.tolerance, args.max_epochs)
+        ijk_all = np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])] for b in range(B)], np.int64)
+        whole = torch.empty(B * bdims[0] * bdims[1] * bdims[2], dtype=torch.uint8, device="cuda")
+        img = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+        cam, P = vr.default_camera(), vr.default_params(1920, 1080, (256, 256, 128))
+        first = []
+
+        def on_decoded(t, vol, stream):
+            vr.assemble_bricks(vol, bdims, ijk_all, grid, out=whole, stream=stream)
+            vr.raycast(whole, gdims, cam, P, img, stream=stream)
+            if not first:
+                stream.synchronize()
+                first.append(time.perf_counter())
+
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        st.run(src, on_decoded=on_decoded)
+        wall = time.perf_counter() - w0
+        return {"timesteps": timesteps, "brick_files": timesteps * B, "bytes_per_timestep": int(B * bdims[0] * bdims[1] * bdims[2]),
+                "disk_to_first_frame_ms": round((first[0] - w0) * 1e3, 1), "wall_s": round(wall, 3)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -702,6 +767,20 @@ def main():
             res["config5"] = config5_leg(torch, vr, vox4, gdims, bdims, grid, args)
         except Exception as ex:       # an extra: never lets the headline line go missing
             res["config5"] = {"error": repr(ex)[:300]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        try:
+            res["config5_disk_stage"] = disk_stage_leg(torch, vr, vox4, gdims, bdims, grid, args)
+        except Exception as ex:
+            res["config5_disk_stage"] = {"error": repr(ex)[:300]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        try:
+            res["general_extents"] = general_extents_leg(torch, vr)
+        except Exception as ex:
+            res["general_extents"] = {"error": repr(ex)[:300]}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(vox4, B, V, args.tolerance, args.max_epochs, args.cpu_seconds)
     if rank == 0:

@@ -184,7 +184,6 @@ def test_tree_29_levels_deep_against_the_oracle(oracle, tmp_path):
     _big_single_tree(oracle, (2048, 2048, 192), tmp_path, oracle_build=True)
 
 
-@pytest.mark.skipif(os.environ.get("VRHIP_BIG_TESTS") != "1", reason="minutes of host time: VRHIP_BIG_TESTS=1")
 def test_the_references_own_volume_2048x2048x768(oracle, tmp_path):
     """main.cpp:242-281 at its real size: 384 bricks assembled into 2048 x 2048 x 768, ONE tree (origTreeDepth 31,
     2^31 leaves for 3.2 G voxels), save, levelCut.  The oracle walks the stream the GPU wrote (levelCut on the saved file)
