@@ -1197,7 +1197,11 @@ k_decode_quad(TileArgs a)
 #ifndef RG_PER
 #define RG_PER 16           // regions per workgroup
 #endif
-#define RG_WAVES 8
+#ifndef RG_WAVES
+#define RG_WAVES 8          // emit blocks (waves) of a region along x: 8 = whole 128-byte lines, 4 = 64-byte half lines
+#endif
+#define RG_LW (RG_WAVES == 8 ? 3 : 2)
+#define RG_REGX (16 * RG_WAVES)
 #define RG_BLK_WORDS 1028
 #define RG_RING_MASK (RG_NP * 256 - 1)
 
@@ -1364,12 +1368,12 @@ k_decode_region(RegionArgs a)
     const int nreg = a.nreg;
     int rid = (int)blockIdx.x;
     if (rid >= nreg) return;
-    // ---- tables (512 threads)
+    // ---- tables
     {
         const uint8_t *dmap = a.ctrls[brick].distanceMap;
         const int t = threadIdx.x;
-        if (t >= 320 && t < 512) {      // rank bits of the coordinates above the emit block (bit deposit, once per workgroup)
-            const int ax = (t - 320) >> 6, v = (t - 320) & 63;
+        if (t < 192) {       // rank bits of the coordinates above the emit block (bit deposit, once per workgroup)
+            const int ax = t >> 6, v = t & 63;
             const uint32_t pos = ax == 0 ? a.blkX : (ax == 1 ? a.blkY : a.blkZ);
             uint32_t r = 0;
 #pragma unroll
@@ -1427,12 +1431,13 @@ k_decode_region(RegionArgs a)
     const uint32_t g = qlow & 15u;
     const uint32_t ownN = g == 0u ? 4u : (uint32_t)(__ffs((int)g) - 1);     // ancestors (depth >= D-6) whose tokens head my run
     const uint32_t p0 = 2u * ownN, p1 = p0 + 2u;                           // bit of my root's token / of my first pair's
-    // my rows of the gather: gather bits 0-2 <- lane >> 3, 3-4 <- the store's index, 5-7 <- wave
+    // my rows of the gather: the 8 - RG_LW low gather bits <- lane >> RG_LW and the store's index (two bits), the RG_LW
+    // high ones <- wave.  (Gather bits 0 .. 5-RG_LW from the lane, then 2 of the store, then the wave's.)
     uint32_t addrL = 0, byteL = 0, outL = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (i == 3 || i == 4) continue;
-        const bool on = i < 3 ? ((lane >> (3 + i)) & 1) != 0 : ((wave >> (i - 5)) & 1) != 0;
+        if (i >= 6 - RG_LW && i < 8 - RG_LW) continue;
+        const bool on = i < 6 - RG_LW ? ((lane >> (RG_LW + i)) & 1) != 0 : ((wave >> (i - (8 - RG_LW))) & 1) != 0;
         addrL ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
         byteL |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
         outL += on ? a.gOut[i] : 0u;
@@ -1455,7 +1460,7 @@ k_decode_region(RegionArgs a)
     for (int i = 0; i < RG_NP; ++i) markP[i] = 0;
     const auto index_of = [&](int r) -> int64_t {       // first index entry of my emit block (the wave-th along x) of region r
         const uint32_t rx = (uint32_t)r & ((1u << a.lrx) - 1u), ry = ((uint32_t)r >> a.lrx) & ((1u << a.lry) - 1u), rz = (uint32_t)r >> (a.lrx + a.lry);
-        const uint32_t blk = smw.blkTab[0][rx * 8u + (uint32_t)wave] | smw.blkTab[1][ry] | smw.blkTab[2][rz];
+        const uint32_t blk = smw.blkTab[0][rx * (uint32_t)RG_WAVES + (uint32_t)wave] | smw.blkTab[1][ry] | smw.blkTab[2][rz];
         return (int64_t)brick * a.nIdx + ((int64_t)blk << 6);
     };
     const auto request_index = [&](int r, int slot) {    // 256 + 64 bytes into index slot `slot`
@@ -1596,7 +1601,7 @@ k_decode_region(RegionArgs a)
         RG_T(2);
         // ---- where this region's voxels go
         const uint32_t rxC = (uint32_t)rid & ((1u << a.lrx) - 1u), ryC = ((uint32_t)rid >> a.lrx) & ((1u << a.lry) - 1u), rzC = (uint32_t)rid >> (a.lrx + a.lry);
-        uint8_t *O = a.out + (int64_t)brick * a.voxels + ((int64_t)rzC * 16 * a.Y + (int64_t)ryC * 16) * a.X + (int64_t)rxC * 128 + (lane & 7) * 16;
+        uint8_t *O = a.out + (int64_t)brick * a.voxels + ((int64_t)rzC * 16 * a.Y + (int64_t)ryC * 16) * a.X + (int64_t)rxC * RG_REGX + (lane & (RG_WAVES - 1)) * 16;
         // ---- the pipeline: the next region staged (the ring is free now; a stale piece of this region still in flight
         // lands before the next region's piece for the same slot: loads return in issue order)
         slot = slot + 1 == RG_IDXD ? 0 : slot + 1;
@@ -1607,15 +1612,15 @@ k_decode_region(RegionArgs a)
         // ---- gather: a 16-byte row piece of emit block c = lane & 7 per lane, eight whole 128-byte lines per store.
         // All reads of the image first (they are independent), then the byte picks and the stores.
         {
-            const uint32_t *img = sm.buf + (lane & 7) * RG_BLK_WORDS;
+            const uint32_t *img = sm.buf + (lane & (RG_WAVES - 1)) * RG_BLK_WORDS;
             const uint32_t xr1 = a.xRead[0] >> 16, xr2 = a.xRead[1] & 0xFFFFu, xr3 = a.xRead[1] >> 16;
             uint32_t addrI[4], bselI[4], ooI[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 uint32_t addr = addrL, bsel = byteL, oo = outL;
 #pragma unroll
-                for (int i = 3; i < 5; ++i) {
-                    const bool on = ((it >> (i - 3)) & 1) != 0;
+                for (int i = 6 - RG_LW; i < 8 - RG_LW; ++i) {
+                    const bool on = ((it >> (i - (6 - RG_LW))) & 1) != 0;
                     addr ^= on ? (a.gAddr[i >> 1] >> (16 * (i & 1))) & 0xFFFFu : 0u;
                     bsel |= on ? (a.gByte >> (4 * i)) & 15u : 0u;
                     oo += on ? a.gOut[i] : 0u;
@@ -1722,7 +1727,7 @@ static bool region_geometry(const BrickSet *bs, RegionArgs &a)
     const Geom &g = bs->g;
     const int D = g.D;
     if (bs->K != 6 || D < 12 || bs->generalGeom || bs->idx64 || (bs->treeCap & 15)) return false;
-    if (g.X < 128 || g.Y < 16 || g.Z < 16) return false;
+    if (g.X < RG_REGX || g.X < 128 || g.Y < 16 || g.Z < 16) return false;
     if ((g.X & (g.X - 1)) || (g.Y & (g.Y - 1)) || (g.Z & (g.Z - 1))) return false;
     int pos[3] = {-1, -1, -1};
     for (int q = 0; q < 3; ++q) pos[g.axis[D - 3 + q]] = 2 - q;           // deepest level -> rank bit 0
@@ -1773,9 +1778,10 @@ static bool region_geometry(const BrickSet *bs, RegionArgs &a)
             b.byte = rb < 2 ? 1u << rb : 0u;
             b.out = ax == 1 ? (uint32_t)((1 << k) * g.X) : (uint32_t)((int64_t)(1 << k) * g.X * g.Y);
         }
-    // gather bits 0-2 come from lane >> 3: bit 1 the plane bit at image bit 5 (the 16-byte bank slot's top bit), bits 0
-    // and 2 plane bits that do not move the slot at all (byte index, image bit 9): the eight rows of a store instruction
-    // then read conflict-free (the lanes of one row are the eight emit blocks, 4 words = one slot apart)
+    // gather bits 0 .. 5-RG_LW come from lane >> RG_LW.  Eight emit blocks per region: bit 1 the plane bit at image bit 5
+    // (the 16-byte bank slot's top bit), bits 0 and 2 plane bits that do not move the slot at all (byte index, image bit
+    // 9): the eight rows of a store instruction then read conflict-free (the lanes of one row are the eight emit blocks,
+    // 4 words = one slot apart).  Four blocks per region: the same three first, any fourth (a two-way conflict at worst).
     bool used[8] = {false, false, false, false, false, false, false, false};
     int n = 0;
     const auto take = [&](int i) { ord[n++] = bits[i]; used[i] = true; };
@@ -1803,9 +1809,9 @@ static bool region_geometry(const BrickSet *bs, RegionArgs &a)
     a.xRead[1] = xr[2] | (xr[3] << 16);
     a.jx = jx;
     a.X = g.X; a.Y = g.Y; a.voxels = g.voxels;
-    a.lrx = 0; while ((128 << a.lrx) < g.X) ++a.lrx;
+    a.lrx = 0; while ((RG_REGX << a.lrx) < g.X) ++a.lrx;
     a.lry = 0; while ((16 << a.lry) < g.Y) ++a.lry;
-    a.nreg = (g.X / 128) * (g.Y / 16) * (g.Z / 16);
+    a.nreg = (g.X / RG_REGX) * (g.Y / 16) * (g.Z / 16);
     // the emit block of a 16^3 box: the rank bits above the twelve lowest
     uint32_t bpos[3] = {0, 0, 0};
     for (int d = 0; d < D - 12; ++d) {
