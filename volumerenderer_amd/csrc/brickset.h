@@ -9,7 +9,7 @@ namespace vr {
 struct Stream2 {              // one 2-bit stream (mid, or MidRangeTree's half-range stream)
     uint8_t *temp = nullptr;  // B * heapStride   truth heap (midrange / half range), 1-based
     uint8_t *codes = nullptr; // B * codeStride   2-bit codes, four per byte (TwoBitArray packing), 1-based heap (BFS)
-    uint8_t *recon[3] = {nullptr, nullptr, nullptr}; // B * leafStride each: parents + two level buffers
+    uint8_t *recon[3] = {nullptr, nullptr, nullptr}; // B * reconStride each: parents + two level buffers
     Ctrl *ctrl = nullptr;     // B
     uint8_t *tree = nullptr;  // B * treeCap      the stream the decoders read: the reference's contiguous preorder stream (TwoBitArray
                               //                  packing) or, after a fused build, its block-gapped form (BrickSet::gapped)
@@ -42,7 +42,12 @@ struct BrickSet {
     int32_t Ds = 0;           // D - K
     int64_t heapStride = 0;   // 2^(D+1)
     int64_t leafStride = 0;   // 2^D
-    int64_t codeStride = 0;   // bytes of packed BFS codes per brick: heapStride / 4, 4-byte aligned
+    int64_t codeStride = 0;   // bytes of packed BFS codes per brick: heapStride / 4, 4-byte aligned (leafless builds: the levels above the leaves only)
+    int64_t reconStride = 0;  // bytes per brick of a reconstruction buffer: 2^D, or 2^(D-1) in a leafless build
+    // A fused build (k_prune_emit12) never stores the leaf level's codes and reconstruction: its leaf-level fills only
+    // sum errors, and the prune recomputes both from (truth, parent's reconstruction, the distances the level loop ended
+    // with: Ctrl::finalReconDist / finalCodesDist).  Decided when the encoder's buffers are allocated (first build).
+    bool leafless = false;
     int64_t treeCap = 0;      // bytes per brick reserved for the preorder stream
     int64_t nIdx = 0;         // 2^Ds index entries per brick
 

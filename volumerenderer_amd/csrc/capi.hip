@@ -118,11 +118,7 @@ static vr_status alloc_stream2(BrickSet &b, Stream2 &s, bool encoder)
     HIPCHK(hipMalloc(&s.ctrl, B * sizeof(Ctrl)));
     HIPCHK(hipMemset(s.ctrl, 0, B * sizeof(Ctrl)));
     HIPCHK(hipMalloc(&s.tree, B * (size_t)b.treeCap));
-    if (encoder) {
-        HIPCHK(hipMalloc(&s.temp, B * (size_t)b.heapStride));
-        HIPCHK(hipMalloc(&s.codes, B * (size_t)b.codeStride));
-        for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&s.recon[i], B * (size_t)b.leafStride));
-    }
+    (void)encoder;      // (the encoder's arrays are made by ensure_encoder_buffers at the first build)
     return VR_OK;
 }
 
@@ -144,15 +140,21 @@ static void free_encoder_buffers(BrickSet &b)
 static vr_status alloc_encoder_buffers(BrickSet &b)
 {
     const size_t B = (size_t)b.B;
+    // a fused build (k_prune_emit12: D >= 12, 64-leaf index granularity, not switched off) with a level loop that runs
+    // keeps nothing of the leaf level: codes and reconstruction arrays end one level higher (BrickSet::leafless).
+    // The switch is final here: vr_brickset_set_switch("no_fused_emit") is refused after the first build.
+    b.leafless = b.D >= 12 && b.K == 6 && !b.sw.noFusedEmit && b.maxEpochs >= 1;
+    b.reconStride = b.leafless ? b.leafStride / 2 : b.leafStride;
+    b.codeStride = b.leafless ? b.leafStride / 4 + 16 : ((b.heapStride + 15) / 16) * 4;
     HIPCHK(hipMalloc(&b.mid.temp, B * (size_t)b.heapStride));
     HIPCHK(hipMalloc(&b.mid.codes, B * (size_t)b.codeStride));
-    for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.mid.recon[i], B * (size_t)b.leafStride));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.mid.recon[i], B * (size_t)b.reconStride));
     if (b.variant == VR_VARIANT_MIDRANGE) {
         if (!b.rng.ctrl) HIPCHK(hipMalloc(&b.rng.ctrl, B * sizeof(Ctrl)));       // (an opened MidRangeTree file has these already)
         if (!b.rng.tree) HIPCHK(hipMalloc(&b.rng.tree, B * (size_t)b.treeCap));
         HIPCHK(hipMalloc(&b.rng.temp, B * (size_t)b.heapStride));
         HIPCHK(hipMalloc(&b.rng.codes, B * (size_t)b.codeStride));
-        for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.rng.recon[i], B * (size_t)b.leafStride));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipMalloc(&b.rng.recon[i], B * (size_t)b.reconStride));
     }
     const int64_t mm = (int64_t)1 << (b.D > 10 ? b.D - 10 : 0);
     for (int i = 0; i < 2; ++i) {
@@ -259,7 +261,8 @@ vr_status vr_brickset_create(vr_brickset **out, int32_t num_bricks, const int64_
     b.Ds = b.D - b.K;
     b.heapStride = (int64_t)1 << (b.D + 1);
     b.leafStride = (int64_t)1 << b.D;
-    b.codeStride = ((b.heapStride + 15) / 16) * 4;
+    b.codeStride = ((b.heapStride + 15) / 16) * 4;     // (both final when the encoder's buffers are made: alloc_encoder_buffers)
+    b.reconStride = b.leafStride;
     const int64_t numMax = b.heapStride - 1 + VR_CHAIN_LEVELS * b.leafStride; // numMaxNodes R.cpp:35
     b.treeCap = ((numMax + 15) / 16 + 2) * 4 + 256;   // slack: the decoder stages whole words past a run's end
     if (b.D >= 12) {   // a fused build keeps every 4096-leaf block's string in a fixed slot of 2320 words (kd_encode.hip PE_WORDS)
@@ -362,6 +365,12 @@ vr_status vr_brickset_build(vr_brickset *h, const uint8_t *vox, void *stream)
 {
     if (!h || !vox) return VR_ERR_INVALID;
     BrickSet &b = h->s;
+    // (vr_brickset_set_max_epochs(0) <-> >= 1 between two builds changes what the level loop keeps of the leaf level:
+    // the encoder's arrays are made again for the other mode)
+    if (b.encoderReady && b.leafless != (b.D >= 12 && b.K == 6 && !b.sw.noFusedEmit && b.maxEpochs >= 1)) {
+        HIPCHK(hipDeviceSynchronize());
+        free_encoder_buffers(b);
+    }
     vr_status rc = ensure_encoder_buffers(b);
     if (rc != VR_OK) return rc;
     b.hostCtrlValid = false;

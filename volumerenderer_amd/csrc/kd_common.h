@@ -62,6 +62,10 @@ struct Ctrl {
     int32_t emitOverflow;    // emit refused to write past the stream buffer (internal error)
     int32_t constBrick;      // every voxel of the brick has the same value: closed-form result (k_const_finish)
     int32_t constVal;
+    // which distance the reconstruction in each of the two level buffers (by role) was filled with, and the codes in
+    // memory (every fill overwrites them, a revert does not restore them: SURVEY C-2); k_level_end keeps the finished
+    // level's pair, which after the loop is the leaf level's: what a leafless build recomputes the leaves from
+    int32_t roleDist[2], codesDist, finalReconDist, finalCodesDist;
     int32_t zeroRun;         // grown branches that ended on an evaluated "keep" code: the reference would rewrite that
                              // run of zeros to 3s (R.cpp:662-669,686-688).  Provably never happens for tolerance >= 0
                              // (the last distance is 1), so the emitters do not implement the rewrite; they count here

@@ -714,11 +714,48 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// Codes and reconstructions of 16 consecutive nodes (eight sibling pairs) from their truths and parents at one distance,
+// in the formats k_fill16 stores (codes: 2 bits per node in node order; reconstructions: a byte per node).  k_prune_emit12
+// recomputes the leaf level of a leafless build with it.
+__device__ __forceinline__ void pairs16_codes_recon(const uint32_t tw[4], const uint32_t pw[2], uint32_t d2, uint32_t &cpk, uint32_t rw[4])
+{
+    uint32_t wa = 0, wb = 0, rprev = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
+        const vr_s16x2 x = enc_pair_x(c, d2), ax = pk_abs(x);
+        const uint32_t take = pk_u((ax - c.pd) >> 15);
+        const uint32_t code2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));
+        if (j < 4) wa |= code2 << (4 * j); else wb |= code2 << (4 * (j - 4));
+        const vr_s16x2 r = pk_mad(x, pk_mad(pk_s(c.up), pk_s(0xFFFEFFFEu), pk_s(0xFFFFFFFFu)), c.T2);
+        const uint32_t rec = (take & pk_u(r)) | (~take & pk_u(c.P2));
+        if (j & 1) rw[j >> 1] = __builtin_amdgcn_perm(rec, rprev, 0x06040200u); else rprev = rec;
+    }
+    cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
+}
+// the leaf level as the level loop left it: codes at the distance of the last fill, reconstruction at the distance of the
+// buffer the loop ended on (they differ after a reverted epoch: the reference restores the reconstruction, not the codes)
+__device__ __forceinline__ void leaves16_recompute(const uint4 &tv, const uint2 &pv, int distRecon, int distCodes, uint32_t &cpk, uint4 &rv)
+{
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
+    const uint32_t differs = (tw[0] ^ __builtin_amdgcn_perm(0, pw[0], 0x01010000u)) | (tw[1] ^ __builtin_amdgcn_perm(0, pw[0], 0x03030202u)) |
+                             (tw[2] ^ __builtin_amdgcn_perm(0, pw[1], 0x01010000u)) | (tw[3] ^ __builtin_amdgcn_perm(0, pw[1], 0x03030202u));
+    cpk = 0; rv = tv;                       // every truth equal to its parent's reconstruction: all "keep", exact
+    if (__ballot(differs != 0u) == 0ull) return;
+    uint32_t rw[4];
+    pairs16_codes_recon(tw, pw, (uint32_t)distRecon * 0x10001u, cpk, rw);
+    rv = make_uint4(rw[0], rw[1], rw[2], rw[3]);
+    if (distCodes != distRecon) {           // (uniform per brick)
+        uint32_t dummy[4];
+        pairs16_codes_recon(tw, pw, (uint32_t)distCodes * 0x10001u, cpk, dummy);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
          int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk,
-         SkipBlocks sk)
-{
+         SkipBlocks sk, int store)
+{   // store == 0 (the leaf level of a leafless build): errors only -- k_prune_emit12 recomputes codes and reconstruction
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
     // everything the wave needs from the brick's control block is fetched in ONE scalar round trip, before the
@@ -764,12 +801,14 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
         const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
         const vr_s16x2 x = enc_pair_x(c, d2), ax = pk_abs(x);
         e0 = pk_sumsq(__builtin_elementwise_min(c.pd, ax), e0);
+        if (store) {
         const uint32_t take = pk_u((ax - c.pd) >> 15);                 // 0xFFFF per lane where |x| < pd
         const uint32_t code2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));   // up ? 1 : 2 (per-lane wrap)
         if (j < 4) wa |= code2 << (4 * j); else wb |= code2 << (4 * (j - 4));
         const vr_s16x2 r = pk_mad(x, pk_mad(pk_s(c.up), pk_s(0xFFFEFFFEu), pk_s(0xFFFFFFFFu)), c.T2);   // up ? t + x : t - x  (sign = -2 up - 1)
         const uint32_t rec = (take & pk_u(r)) | (~take & pk_u(c.P2));
         if (j & 1) rw[j >> 1] = __builtin_amdgcn_perm(rec, rprev, 0x06040200u); else rprev = rec;
+        }
         if (needDF) {
             em = pk_sumsq(enc_pair_err(c, dm2), em);
             ep = pk_sumsq(enc_pair_err(c, dp2), ep);
@@ -777,7 +816,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     }
     // even nodes sit at bits 4j, odd ones at 16+4j: fold to 2 bits per node
     const uint32_t cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
-    if (!skipped) {
+    if (!skipped && store) {
         st4(Cd + (i0 >> 2), cpk);
         st16(R + i0, make_uint4(rw[0], rw[1], rw[2], rw[3]));
     }
@@ -991,6 +1030,8 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
     }
     if (lane != 0) return;
     if (ending) {
+        c.roleDist[c.cur] = (int)(uint8_t)c.currentDistance;   // what this epoch's fill wrote its buffer and the codes with
+        c.codesDist = (int)(uint8_t)c.currentDistance;
         c.currentError = s / (double)n;                        // R.cpp:315
         if (c.currentError < 1.0) {                            // R.cpp:319
             c.active = 0;
@@ -1043,6 +1084,8 @@ __global__ void k_level_end(int d, Ctrl *ctrls)
     if (c.constBrick) return;
     c.distanceMap[d] = (uint8_t)c.currentDistance;
     int finalRole = c.pendingEqual ? c.prev : c.cur;
+    c.finalReconDist = c.roleDist[finalRole];
+    c.finalCodesDist = c.codesDist;
     int finalPhys = phys_buf(c, finalRole);
     int otherPhys = phys_buf(c, 1 - finalRole);
     int oldPar = c.par;
@@ -1513,6 +1556,7 @@ struct PruneEmitArgs {
     uint8_t *gap, *gapR;           // the streams' block-gapped buffers (Stream2::tree)
     int64_t treeCap;
     SkipBlocks sk, skR;            // blocks the level loop left alone below depth D-2: all "keep", exactly reproduced (per stream)
+    int leafless;                  // the leaf level's codes and reconstruction are not in memory: recomputed here (BrickSet::leafless)
 };
 
 __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
@@ -1544,7 +1588,7 @@ k_prune_emit12(PruneEmitArgs a)
     __shared__ uint32_t shw[4];
     const int brick = blockIdx.y, t = threadIdx.x, D = a.D, tol = a.tol;
     Ctrl &c = a.ctrls[brick];
-    const int cConst = c.constBrick, cPar = c.par;     // one scalar round trip
+    const int cConst = c.constBrick, cPar = c.par, cRa = c.ra, cDistR = c.finalReconDist, cDistC = c.finalCodesDist;     // one scalar round trip
     if (cConst) return;
     const uint32_t blk = blockIdx.x, base = blk << 12;
     uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
@@ -1562,28 +1606,44 @@ k_prune_emit12(PruneEmitArgs a)
     const bool skipB = a.sk.flag && (a.sk.flag[(int64_t)brick * a.sk.nBlk + blk] & 2u) != 0u;
     uint32_t c1H = 0, cpk = 0;
     uint4 tv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
+    uint2 pv = make_uint2(0, 0), pvR = make_uint2(0, 0);      // leafless: my leaves' eight parents (the level loop's last parents buffer but one)
     if (!skipB) {
         c1H = *(const uint16_t *)(Cb + (n1 >> 2));
-        cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
         tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
-        rv = *(const uint4 *)((cPar == 0 ? a.rb.b[0] : (cPar == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+        if (a.leafless)
+            pv = *(const uint2 *)((cRa == 0 ? a.rb.b[0] : (cRa == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + (base >> 1) + t * 8);
+        else {
+            cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
+            rv = *(const uint4 *)((cPar == 0 ? a.rb.b[0] : (cPar == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+        }
     }
     // RANGE: the same pieces of the range stream
     uint8_t *CbR = RANGE ? a.codesR + (int64_t)brick * a.codeStride : nullptr;
     uint32_t upBR = 0, c4BR = 0, c3BR = 0, c2BR = 0, c1HR = 0, cpkR = 0;
     uint4 tvR = make_uint4(0, 0, 0, 0), rvR = make_uint4(0, 0, 0, 0);
+    int cDistRR = 0, cDistCR = 0;
+    bool skipBR = false;
     if (RANGE) {
         const Ctrl &cr = a.ctrlsR[brick];
-        const int cParR = cr.par;
+        const int cParR = cr.par, cRaR = cr.ra;
+        cDistRR = cr.finalReconDist; cDistCR = cr.finalCodesDist;
         upBR = CbR[niU >> 2]; c4BR = CbR[n4 >> 2]; c3BR = CbR[n3 >> 2]; c2BR = CbR[n2 >> 2];
         // (a block the range stream's level loop skipped: all "keep" and exact there, like the mid stream's above)
-        const bool skipBR = a.skR.flag && (a.skR.flag[(int64_t)brick * a.skR.nBlk + blk] & 2u) != 0u;
+        skipBR = a.skR.flag && (a.skR.flag[(int64_t)brick * a.skR.nBlk + blk] & 2u) != 0u;
         if (!skipBR) {
             c1HR = *(const uint16_t *)(CbR + (n1 >> 2));
-            cpkR = *(const uint32_t *)(CbR + (li >> 2));
             tvR = *(const uint4 *)(a.tempR + (int64_t)brick * a.heapStride + li);
-            rvR = *(const uint4 *)((cParR == 0 ? a.rbR.b[0] : (cParR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+            if (a.leafless)
+                pvR = *(const uint2 *)((cRaR == 0 ? a.rbR.b[0] : (cRaR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + (base >> 1) + t * 8);
+            else {
+                cpkR = *(const uint32_t *)(CbR + (li >> 2));
+                rvR = *(const uint4 *)((cParR == 0 ? a.rbR.b[0] : (cParR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + base + t * 16);
+            }
         }
+    }
+    if (a.leafless) {
+        if (!skipB) leaves16_recompute(tv, pv, cDistR, cDistC, cpk, rv);
+        if (RANGE && !skipBR) leaves16_recompute(tvR, pvR, cDistRR, cDistCR, cpkR, rvR);
     }
     lutS[t] = lutV; lutS[256 + t] = lutV2;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
@@ -2627,7 +2687,7 @@ static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uin
     const int D = bs->D, B = nb < 0 ? bs->B : nb;
     struct { Ctrl *ctrl; uint8_t *temp, *codes; uint8_t *recon[3]; } s;
     s.ctrl = s0.ctrl + b0; s.temp = s0.temp + (int64_t)b0 * bs->heapStride; s.codes = s0.codes + (int64_t)b0 * bs->codeStride;
-    for (int i = 0; i < 3; ++i) s.recon[i] = s0.recon[i] + (int64_t)b0 * bs->leafStride;
+    for (int i = 0; i < 3; ++i) s.recon[i] = s0.recon[i] + (int64_t)b0 * bs->reconStride;
     blockErr += (int64_t)b0 * bs->nErrBlk;
     void *estSumm = (uint32_t *)estSumm0 + (int64_t)b0 * bs->estSummStride * (4 * EST_CAND);
     if (sk.flag) sk.flag += (int64_t)b0 * sk.nBlk;
@@ -2636,34 +2696,35 @@ static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uin
     const int guarded = bs->variant != 0; // GUARDED and MIDRANGE both carry the :333/:340 guard
     hipLaunchKernelGGL(k_ctrl_init, dim3(B), dim3(64), 0, st, s.ctrl, rootMin, rootMax, mmStride);
     if (bs->maxEpochs <= 0) { // the loop never runs: tree.resize() / recon.resize() zero-fill is the result
-        for (int i = 0; i < 3; ++i) hipMemsetAsync(s.recon[i], 0, (size_t)B * bs->leafStride, st);
+        for (int i = 0; i < 3; ++i) hipMemsetAsync(s.recon[i], 0, (size_t)B * bs->reconStride, st);
         hipMemsetAsync(s.codes, 0, (size_t)B * bs->codeStride, st);
     }
     for (int d = 0; d <= D; ++d) {
         const int64_t n = (int64_t)1 << d;
         hipLaunchKernelGGL(k_est_head, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, s.ctrl, s.temp, bs->heapStride, rb,
-                           bs->leafStride, sk);
+                           bs->reconStride, sk);
         if (n > EST_HEAD) {
             const int64_t nseg = n / EST_SEG - EST_HEAD / EST_SEG;
             for (int r = 0; r < EST_ROUNDS; ++r) {
                 const int nc = r < 2 ? 4 : EST_CAND, ncNext = r + 1 < 2 ? 4 : EST_CAND;   // two 4-wide windows, then 8-wide ones
                 const unsigned gx = r == 0 ? cdiv(nseg, 16) : (cdiv(nseg, 4) < 64 ? cdiv(nseg, 4) : 64);   // four segments per wave first
                 hipLaunchKernelGGL(k_est_summ, dim3(gx, B), dim3(256), 0, st, d, nc, s.ctrl, s.temp,
-                                   bs->heapStride, rb, bs->leafStride, (uint32_t *)estSumm, bs->estSummStride, sk);
+                                   bs->heapStride, rb, bs->reconStride, (uint32_t *)estSumm, bs->estSummStride, sk);
                 hipLaunchKernelGGL(k_est_walk, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, nc, ncNext,
-                                   r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->leafStride,
+                                   r == EST_ROUNDS - 1 ? 1 : 0, s.ctrl, s.temp, bs->heapStride, rb, bs->reconStride,
                                    (const uint32_t *)estSumm, bs->estSummStride, sk);
             }
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
                 hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, bs->maxEpochs, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, blockErr, bs->nErrBlk, sk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr, bs->nErrBlk, sk,
+                                   (bs->leafless && d == D) ? 0 : 1);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->leafStride, blockErr, bs->nErrBlk);
+                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr, bs->nErrBlk);
             hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, guarded, s.ctrl, s.temp,
-                               bs->heapStride, rb, bs->leafStride, blockErr, bs->nErrBlk);
+                               bs->heapStride, rb, bs->reconStride, blockErr, bs->nErrBlk);
         }
         hipLaunchKernelGGL(k_level_end, dim3(B), dim3(64), 0, st, d, s.ctrl);
     }
@@ -2697,7 +2758,7 @@ static void fill_emit_args(BrickSet *bs, EmitArgs &a)
     a.rb = ReconBufs{{bs->mid.recon[0], bs->mid.recon[1], bs->mid.recon[2]}};
     a.rbR = ReconBufs{{bs->rng.recon[0], bs->rng.recon[1], bs->rng.recon[2]}};
     a.ctrls = bs->mid.ctrl; a.ctrlsR = mr ? bs->rng.ctrl : nullptr;
-    a.heapStride = bs->heapStride; a.leafStride = bs->leafStride; a.codeStride = bs->codeStride;
+    a.heapStride = bs->heapStride; a.leafStride = bs->reconStride; a.codeStride = bs->codeStride;
     a.D = bs->D; a.maxDepth = bs->maxDepth; a.tol = bs->tolerance; a.Ds = bs->Ds; a.K = bs->K;
     a.blockTot = bs->blockTot; a.blockOff = bs->blockOff; a.nEmitBlk = bs->nEmitBlk;
     a.blockOff64 = bs->blockOff64; a.idxBase = bs->idxBase;
@@ -2771,6 +2832,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     hipEventRecord(bs->ev[0], st);
     const uint8_t *rootMinP = nullptr, *rootMaxP = nullptr;   // where the last pyramid round leaves each brick's root (min,max)
     const bool fused = D >= 12 && bs->K == 6 && !bs->sw.noFusedEmit;   // prune + block-local emit in one kernel
+    if (bs->leafless != (fused && bs->maxEpochs >= 1)) return -2;      // (the arrays were sized for the other mode: capi alloc_encoder_buffers)
     // SkipBlocks needs k_pyramid12's constant bit in front and k_prune_emit12 behind, a prune that makes such blocks
     // one token (tolerance >= 1) and a level loop that runs
     bool skipOn = fused && bs->blockFlag && (!mr || bs->blockFlagR) && bs->tolerance >= 1 && bs->maxEpochs >= 1 && D >= 14 && !bs->sw.noSkipBlocks;
@@ -2891,7 +2953,8 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.sk = sk; pa.skR = skR;
         pa.D = D; pa.tol = bs->tolerance; pa.maxDepth = bs->maxDepth; pa.ctrls = bs->mid.ctrl;
         pa.temp = bs->mid.temp; pa.codes = bs->mid.codes;
-        pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->leafStride;
+        pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->reconStride;
+        pa.leafless = bs->leafless ? 1 : 0;
         pa.rb = rb; pa.subTok = bs->blockOff; pa.nEmitBlk = bs->nEmitBlk; pa.blockL1 = bs->blockL1;
         pa.chainLut = bs->chainLut; pa.idxOff = bs->idxOff; pa.nIdx = bs->nIdx;
         if (!bs->fineIdx && hipMalloc(&bs->fineIdx, (size_t)B * bs->nIdx * 16) != hipSuccess) return -3;
@@ -2907,14 +2970,14 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     } else if (D >= 12) {
         hipLaunchKernelGGL(k_prune12, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
-                           bs->codeStride, rb, bs->leafStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
+                           bs->codeStride, rb, bs->reconStride, bs->maxDepth, (!mr && bs->K >= 2) ? bs->blockOff : nullptr,
                            bs->nEmitBlk,    // per-brick stride of the block arrays (same as EmitArgs::nEmitBlk)
                            bs->blockL1, bs->chainLut);
         pruneFrom = D - 13;
     } else
         hipLaunchKernelGGL(k_prune_leaf, dim3(cdiv((int64_t)1 << D, 256), B), dim3(256), 0, st, D, bs->tolerance,
                            bs->mid.ctrl, bs->mid.temp, bs->mid.codes, mr ? bs->rng.codes : nullptr, bs->heapStride,
-                           bs->codeStride, rb, bs->leafStride, bs->maxDepth, bs->blockL1, bs->nEmitBlk);
+                           bs->codeStride, rb, bs->reconStride, bs->maxDepth, bs->blockL1, bs->nEmitBlk);
     for (int d = pruneFrom; d >= 0; --d)
         hipLaunchKernelGGL(k_prune_level, dim3(cdiv((int64_t)1 << d, 256), B), dim3(256), 0, st, d, bs->mid.ctrl, bs->mid.codes,
                            mr ? bs->rng.codes : nullptr, bs->codeStride);
