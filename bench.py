@@ -472,6 +472,8 @@ def main():
     # first of them, so no further set (65 GB at the full volume) is allocated after the pipelined ones
     NS = args.pipeline                 # bricksets in flight
     sets = []
+    torch.cuda.synchronize()
+    free_before_sets = torch.cuda.mem_get_info()[0]      # the library allocates with hipMalloc, outside torch's caching allocator
     while True:
         try:
             sets = [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
@@ -489,6 +491,9 @@ def main():
             torch.cuda.empty_cache()
             NS -= 1
     bs = sets[0]
+    # device memory a brickset holds once it has built and decoded (encoder arrays, gapped + contiguous stream, decode
+    # side-cars, control blocks): measured, not summed from a table
+    device_bytes_per_set = (free_before_sets - torch.cuda.mem_get_info()[0]) // NS
     # every set on its own stream, decoding into its own output volume: build + levelCut of step k run beside those of
     # steps k+1 .. k+NS-1 (measured against two build streams + one decode stream: 36.1 instead of 37.6 ms per step)
     streams = [torch.cuda.Stream() for _ in range(NS)]
@@ -628,6 +633,8 @@ def main():
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
+           "device_bytes_per_set": int(device_bytes_per_set), "device_bytes_per_set_over_input": round(device_bytes_per_set / float(V * B), 3),
+           "device_bytes_pipeline": int(device_bytes_per_set * NS + vox.numel() * (1 + NS)),
            "serial_ms_per_step": round(sum(enc_ms) / len(enc_ms) + dec_avg_s * 1e3, 3),
            "encode_ms": round(sum(enc_ms) / len(enc_ms), 3), "decode_ms": round(dec_avg_s * 1e3, 3),
            "phases_ms": {k: round(v, 3) for k, v in phases.items()},

@@ -714,48 +714,31 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-// Codes and reconstructions of 16 consecutive nodes (eight sibling pairs) from their truths and parents at one distance,
-// in the formats k_fill16 stores (codes: 2 bits per node in node order; reconstructions: a byte per node).  k_prune_emit12
-// recomputes the leaf level of a leafless build with it.
-__device__ __forceinline__ void pairs16_codes_recon(const uint32_t tw[4], const uint32_t pw[2], uint32_t d2, uint32_t &cpk, uint32_t rw[4])
+// A sibling pair of leaves as the level loop of a leafless build left it (k_prune_emit12): truth minus reconstruction at
+// the distance of the buffer the loop ended on, codes at the distance of the last fill.  The two differ after a reverted
+// epoch: the reference restores the reconstruction, not the codes (SURVEY C-2).  Same reduced encodeNode as k_fill16.
+__device__ __forceinline__ void leaf_pair_encode(uint32_t tword, int tsel, uint32_t pword, int psel, uint32_t dR2, uint32_t dC2,
+                                                 vr_s16x2 &dl, uint32_t &codes2)
 {
-    uint32_t wa = 0, wb = 0, rprev = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
-        const vr_s16x2 x = enc_pair_x(c, d2), ax = pk_abs(x);
-        const uint32_t take = pk_u((ax - c.pd) >> 15);
-        const uint32_t code2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));
-        if (j < 4) wa |= code2 << (4 * j); else wb |= code2 << (4 * (j - 4));
-        const vr_s16x2 r = pk_mad(x, pk_mad(pk_s(c.up), pk_s(0xFFFEFFFEu), pk_s(0xFFFFFFFFu)), c.T2);
-        const uint32_t rec = (take & pk_u(r)) | (~take & pk_u(c.P2));
-        if (j & 1) rw[j >> 1] = __builtin_amdgcn_perm(rec, rprev, 0x06040200u); else rprev = rec;
+    const EncPair c = enc_pair(tword, tsel, pword, psel);
+    const vr_s16x2 x = enc_pair_x(c, dR2), nx = (vr_s16x2)(0) - x, ax = __builtin_elementwise_max(x, nx);
+    uint32_t take = pk_u((ax - c.pd) >> 15);                                 // 0xFFFF per lane where |x| < pd: the step is taken
+    // reconstruction = up ? t + x : t - x where taken, the parent's otherwise
+    const uint32_t stepD = (c.up & pk_u(nx)) | (~c.up & pk_u(x));
+    dl = pk_s((take & stepD) | (~take & pk_u(c.T2 - c.P2)));
+    if (dC2 != dR2) {                                                        // (uniform per brick)
+        const vr_s16x2 xc = enc_pair_x(c, dC2);
+        take = pk_u((pk_abs(xc) - c.pd) >> 15);
     }
-    cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
-}
-// the leaf level as the level loop left it: codes at the distance of the last fill, reconstruction at the distance of the
-// buffer the loop ended on (they differ after a reverted epoch: the reference restores the reconstruction, not the codes)
-__device__ __forceinline__ void leaves16_recompute(const uint4 &tv, const uint2 &pv, int distRecon, int distCodes, uint32_t &cpk, uint4 &rv)
-{
-    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
-    const uint32_t differs = (tw[0] ^ __builtin_amdgcn_perm(0, pw[0], 0x01010000u)) | (tw[1] ^ __builtin_amdgcn_perm(0, pw[0], 0x03030202u)) |
-                             (tw[2] ^ __builtin_amdgcn_perm(0, pw[1], 0x01010000u)) | (tw[3] ^ __builtin_amdgcn_perm(0, pw[1], 0x03030202u));
-    cpk = 0; rv = tv;                       // every truth equal to its parent's reconstruction: all "keep", exact
-    if (__ballot(differs != 0u) == 0ull) return;
-    uint32_t rw[4];
-    pairs16_codes_recon(tw, pw, (uint32_t)distRecon * 0x10001u, cpk, rw);
-    rv = make_uint4(rw[0], rw[1], rw[2], rw[3]);
-    if (distCodes != distRecon) {           // (uniform per brick)
-        uint32_t dummy[4];
-        pairs16_codes_recon(tw, pw, (uint32_t)distCodes * 0x10001u, cpk, dummy);
-    }
+    codes2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));                   // up ? 1 : 2 (per-lane wrap)
 }
 
+template <bool STORE>     // false (the leaf level of a leafless build): errors only -- k_prune_emit12 recomputes codes and reconstruction
 __global__ void __launch_bounds__(256)
 k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
          int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk,
-         SkipBlocks sk, int store)
-{   // store == 0 (the leaf level of a leafless build): errors only -- k_prune_emit12 recomputes codes and reconstruction
+         SkipBlocks sk)
+{
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
     // everything the wave needs from the brick's control block is fetched in ONE scalar round trip, before the
@@ -801,7 +784,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
         const EncPair c = enc_pair(tw[j >> 1], j & 1, pw[j >> 2], j & 3);
         const vr_s16x2 x = enc_pair_x(c, d2), ax = pk_abs(x);
         e0 = pk_sumsq(__builtin_elementwise_min(c.pd, ax), e0);
-        if (store) {
+        if (STORE) {
         const uint32_t take = pk_u((ax - c.pd) >> 15);                 // 0xFFFF per lane where |x| < pd
         const uint32_t code2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));   // up ? 1 : 2 (per-lane wrap)
         if (j < 4) wa |= code2 << (4 * j); else wb |= code2 << (4 * (j - 4));
@@ -816,7 +799,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     }
     // even nodes sit at bits 4j, odd ones at 16+4j: fold to 2 bits per node
     const uint32_t cpk = ((wa | (wa >> 14)) & 0xFFFFu) | ((wb | (wb >> 14)) << 16);
-    if (!skipped && store) {
+    if (!skipped && STORE) {
         st4(Cd + (i0 >> 2), cpk);
         st16(R + i0, make_uint4(rw[0], rw[1], rw[2], rw[3]));
     }
@@ -1556,7 +1539,6 @@ struct PruneEmitArgs {
     uint8_t *gap, *gapR;           // the streams' block-gapped buffers (Stream2::tree)
     int64_t treeCap;
     SkipBlocks sk, skR;            // blocks the level loop left alone below depth D-2: all "keep", exactly reproduced (per stream)
-    int leafless;                  // the leaf level's codes and reconstruction are not in memory: recomputed here (BrickSet::leafless)
 };
 
 __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned long long v, int ntok)
@@ -1576,7 +1558,7 @@ __device__ __forceinline__ void pe_put(uint32_t *W, uint32_t bitpos, unsigned lo
 // stream's prune decisions and branch lengths from the mid arrays (same code, so the same result), swaps the range
 // stream's values in, and writes the same string shape into the range stream's staging area.  Index, counts and
 // statistics belong to the first launch.
-template <bool RANGE>
+template <bool RANGE, bool LEAFLESS>
 __global__ void __launch_bounds__(256, RANGE ? 4 : 6)
 k_prune_emit12(PruneEmitArgs a)
 {
@@ -1610,7 +1592,7 @@ k_prune_emit12(PruneEmitArgs a)
     if (!skipB) {
         c1H = *(const uint16_t *)(Cb + (n1 >> 2));
         tv = *(const uint4 *)(a.temp + (int64_t)brick * a.heapStride + li);
-        if (a.leafless)
+        if (LEAFLESS)
             pv = *(const uint2 *)((cRa == 0 ? a.rb.b[0] : (cRa == 1 ? a.rb.b[1] : a.rb.b[2])) + (int64_t)brick * a.leafStride + (base >> 1) + t * 8);
         else {
             cpk = *(const uint32_t *)(Cb + (li >> 2));       // my 16 leaf codes, packed
@@ -1633,7 +1615,7 @@ k_prune_emit12(PruneEmitArgs a)
         if (!skipBR) {
             c1HR = *(const uint16_t *)(CbR + (n1 >> 2));
             tvR = *(const uint4 *)(a.tempR + (int64_t)brick * a.heapStride + li);
-            if (a.leafless)
+            if (LEAFLESS)
                 pvR = *(const uint2 *)((cRaR == 0 ? a.rbR.b[0] : (cRaR == 1 ? a.rbR.b[1] : a.rbR.b[2])) + (int64_t)brick * a.leafStride + (base >> 1) + t * 8);
             else {
                 cpkR = *(const uint32_t *)(CbR + (li >> 2));
@@ -1641,9 +1623,12 @@ k_prune_emit12(PruneEmitArgs a)
             }
         }
     }
-    if (a.leafless) {
-        if (!skipB) leaves16_recompute(tv, pv, cDistR, cDistC, cpk, rv);
-        if (RANGE && !skipBR) leaves16_recompute(tvR, pvR, cDistRR, cDistCR, cpkR, rvR);
+    // leafless: the leaf stage below encodes every sibling pair itself; all that is needed up here is "every truth equals
+    // its parent's reconstruction" (then all codes are "keep" and the leaves exact: what cpk == 0, tv == rv say)
+    if (LEAFLESS) {
+        rv = tv;
+        cpk = ((tv.x ^ __builtin_amdgcn_perm(0, pv.x, 0x01010000u)) | (tv.y ^ __builtin_amdgcn_perm(0, pv.x, 0x03030202u)) |
+               (tv.z ^ __builtin_amdgcn_perm(0, pv.y, 0x01010000u)) | (tv.w ^ __builtin_amdgcn_perm(0, pv.y, 0x03030202u))) != 0u ? 1u : 0u;
     }
     lutS[t] = lutV; lutS[256 + t] = lutV2;
     { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
@@ -1674,7 +1659,8 @@ k_prune_emit12(PruneEmitArgs a)
         return;
     }
     // ---- leaves: prune (R.cpp:618-626), grown branches (R.cpp:655-704); sibling leaves share packed 16-bit lanes
-    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w}, pwL[2] = {pv.x, pv.y};
+    const uint32_t dR2 = (uint32_t)cDistR * 0x10001u, dC2 = (uint32_t)cDistC * 0x10001u;
     const uint32_t tol2 = (uint32_t)tol * 0x10001u;
     uint32_t nt[8], Lb[8];      // per lane: tokens the leaf emits when live; its code + grown branch << 2
     uint32_t bothMask = 0;
@@ -1698,13 +1684,18 @@ k_prune_emit12(PruneEmitArgs a)
             const int j = half * 4 + jj;
             const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
             T2[jj] = __builtin_amdgcn_perm(0, tw[j >> 1], sel);
-            const vr_s16x2 dl = pk_s(T2[jj]) - pk_s(__builtin_amdgcn_perm(0, rw[j >> 1], sel));
+            vr_s16x2 dl;
+            uint32_t cl2;                                                                           // the pair's codes
+            if (LEAFLESS) leaf_pair_encode(tw[j >> 1], j & 1, pwL[j >> 2], j & 3, dR2, dC2, dl, cl2);
+            else {
+                dl = pk_s(T2[jj]) - pk_s(__builtin_amdgcn_perm(0, rw[j >> 1], sel));
+                cl2 = ((cpk >> (4 * j)) & 3u) | (((cpk >> (4 * j + 2)) & 3u) << 16);
+            }
             const vr_s16x2 mm = pk_abs(dl);
             m[jj] = pk_u(mm);
             sg[jj] = pk_u(dl >> 15);
             mxB = __builtin_elementwise_max(mxB, mm);
             const uint32_t lt = pk_u((mm - pk_s(tol2)) >> 15);                                     // err < tol
-            const uint32_t cl2 = ((cpk >> (4 * j)) & 3u) | (((cpk >> (4 * j + 2)) & 3u) << 16);     // the pair's codes
             const uint32_t isz = pk_u((pk_s(cl2) - pk_s(0x00010001u)) >> 15), is3 = pk_u((pk_s(0x00020002u) - pk_s(cl2)) >> 15);
             const uint32_t newp = isz & lt;
             const uint32_t pruned = newp | is3;
@@ -1768,13 +1759,19 @@ k_prune_emit12(PruneEmitArgs a)
         // sibling leaves in packed 16-bit lanes, like the mid stream's: per branch level one reduced encodeNode
         // (kd_common.h) for both, applied where the mid stream's branch still has an evaluated node at that level;
         // a wave leaves the level loop as soon as none of its branches is that long
-        const uint32_t twR[4] = {tvR.x, tvR.y, tvR.z, tvR.w}, rwR[4] = {rvR.x, rvR.y, rvR.z, rvR.w};
+        const uint32_t twR[4] = {tvR.x, tvR.y, tvR.z, tvR.w}, rwR[4] = {rvR.x, rvR.y, rvR.z, rvR.w}, pwR[2] = {pvR.x, pvR.y};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (!busy) { LbR[j] = 0x00030003u; continue; }
             const uint32_t sel = (j & 1) ? 0x0c030c02u : 0x0c010c00u;
             const vr_s16x2 T2 = pk_s(__builtin_amdgcn_perm(0, twR[j >> 1], sel));
             vr_s16x2 rec = pk_s(__builtin_amdgcn_perm(0, rwR[j >> 1], sel));
+            uint32_t cR = ((cpkR >> (4 * j)) & 3u) | (((cpkR >> (4 * j + 2)) & 3u) << 16);
+            if (LEAFLESS) {       // the range stream's own leaf level, recomputed like the mid stream's
+                vr_s16x2 dlR;
+                leaf_pair_encode(twR[j >> 1], j & 1, pwR[j >> 2], j & 3, (uint32_t)cDistRR * 0x10001u, (uint32_t)cDistCR * 0x10001u, dlR, cR);
+                rec = T2 - dlR;
+            }
             const uint32_t mid = Lb[j];
             const vr_s16x2 n2 = pk_s(nt[j]) - pk_s(0x00010001u);                        // branch tokens of the mid stream
             const uint32_t prunedM = ((mid & (mid >> 1)) & 0x00010001u) * 0xFFFFu;          // the leaf's own token is a 3
@@ -1783,7 +1780,6 @@ k_prune_emit12(PruneEmitArgs a)
             const uint32_t hasN = pk_u((vr_s16x2)(0) - n2) >> 15 & 0x00010001u;            // n > 0
             const uint32_t termB = (lt & (lt >> 1)) & hasN;                                 // bit 0 of each lane: has a terminator
             const vr_s16x2 k2 = n2 - pk_s(termB);                                           // evaluated branch nodes
-            const uint32_t cR = ((cpkR >> (4 * j)) & 3u) | (((cpkR >> (4 * j + 2)) & 3u) << 16);
             uint32_t bits = (prunedM & 0x00030003u) | (~prunedM & cR);
             for (int i = 0; i < VR_CHAIN_LEVELS; ++i) {
                 const uint32_t am = pk_u((pk_s((uint32_t)i * 0x10001u) - k2) >> 15);       // 0xFFFF where k > i
@@ -2717,9 +2713,9 @@ static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uin
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
-                hipLaunchKernelGGL(k_fill16, dim3((unsigned)(n / 4096), B), dim3(256), 0, st, d, bs->maxEpochs, s.ctrl, s.temp,
-                                   s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr, bs->nErrBlk, sk,
-                                   (bs->leafless && d == D) ? 0 : 1);
+                hipLaunchKernelGGL((bs->leafless && d == D) ? k_fill16<false> : k_fill16<true>, dim3((unsigned)(n / 4096), B), dim3(256), 0, st,
+                                   d, bs->maxEpochs, s.ctrl, s.temp, s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr,
+                                   bs->nErrBlk, sk);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
                                    s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr, bs->nErrBlk);
@@ -2954,7 +2950,6 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.D = D; pa.tol = bs->tolerance; pa.maxDepth = bs->maxDepth; pa.ctrls = bs->mid.ctrl;
         pa.temp = bs->mid.temp; pa.codes = bs->mid.codes;
         pa.heapStride = bs->heapStride; pa.codeStride = bs->codeStride; pa.leafStride = bs->reconStride;
-        pa.leafless = bs->leafless ? 1 : 0;
         pa.rb = rb; pa.subTok = bs->blockOff; pa.nEmitBlk = bs->nEmitBlk; pa.blockL1 = bs->blockL1;
         pa.chainLut = bs->chainLut; pa.idxOff = bs->idxOff; pa.nIdx = bs->nIdx;
         if (!bs->fineIdx && hipMalloc(&bs->fineIdx, (size_t)B * bs->nIdx * 16) != hipSuccess) return -3;
@@ -2963,8 +2958,14 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
         pa.ctrlsR = mr ? bs->rng.ctrl : nullptr; pa.tempR = mr ? bs->rng.temp : nullptr; pa.codesR = mr ? bs->rng.codes : nullptr;
         pa.rbR = rbR;
         pa.gap = bs->mid.tree; pa.gapR = mr ? bs->rng.tree : nullptr; pa.treeCap = bs->treeCap;
-        hipLaunchKernelGGL(k_prune_emit12<false>, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
-        if (mr) hipLaunchKernelGGL(k_prune_emit12<true>, dim3((unsigned)((int64_t)1 << (D - 12)), B), dim3(256), 0, st, pa);
+        const dim3 peGrid((unsigned)((int64_t)1 << (D - 12)), B);
+        if (bs->leafless) {
+            hipLaunchKernelGGL((k_prune_emit12<false, true>), peGrid, dim3(256), 0, st, pa);
+            if (mr) hipLaunchKernelGGL((k_prune_emit12<true, true>), peGrid, dim3(256), 0, st, pa);
+        } else {
+            hipLaunchKernelGGL((k_prune_emit12<false, false>), peGrid, dim3(256), 0, st, pa);
+            if (mr) hipLaunchKernelGGL((k_prune_emit12<true, false>), peGrid, dim3(256), 0, st, pa);
+        }
         pruneFrom = D - 13;
         bs->fineHas.assign((size_t)B, 1);
     } else if (D >= 12) {
