@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_TRAFFIC = "profiles/r02_pmc_hbm_traffic.json"   # separate rocprofv3 --pmc passes of this same command (profiles/refresh_profiles.sh)
+PMC_TRAFFIC = "profiles/r03_pmc_hbm_traffic.json"   # separate rocprofv3 --pmc passes of this same command (profiles/refresh_profiles.sh)
 
 
 def make_bricks(kind, n_bricks, dims, seed=12345):

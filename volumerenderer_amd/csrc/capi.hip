@@ -162,11 +162,11 @@ static vr_status alloc_encoder_buffers(BrickSet &b)
         HIPCHK(hipMalloc(&b.mmMax[i], B * (size_t)mm));
     }
     b.nErrBlk = ((int64_t)1 << b.D) / 1024 > 0 ? ((int64_t)1 << b.D) / 1024 : 1;
-    HIPCHK(hipMalloc(&b.blockErr, B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b.blockErr, 3 * B * (size_t)b.nErrBlk * sizeof(unsigned long long)));     // + the central difference's two planes (Ctrl::altSel)
     b.estSummStride = ((int64_t)1 << b.D) / 1024 > 0 ? ((int64_t)1 << b.D) / 1024 : 1;
     HIPCHK(hipMalloc(&b.estSumm, B * (size_t)b.estSummStride * 128));
     if (b.variant == VR_VARIANT_MIDRANGE) {
-        HIPCHK(hipMalloc(&b.blockErrR, B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&b.blockErrR, 3 * B * (size_t)b.nErrBlk * sizeof(unsigned long long)));
         HIPCHK(hipMalloc(&b.estSummR, B * (size_t)b.estSummStride * 128));
     }
     b.nEmitBlk = (((int64_t)1 << b.D) + 255) / 256;

@@ -66,6 +66,11 @@ struct Ctrl {
     // memory (every fill overwrites them, a revert does not restore them: SURVEY C-2); k_level_end keeps the finished
     // level's pair, which after the loop is the leaf level's: what a leafless build recomputes the leaves from
     int32_t roleDist[2], codesDist, finalReconDist, finalCodesDist;
+    // leaf level of a leafless build: its fills store nothing but error partials, so an epoch at the previous fill's
+    // distance -1 / +1 needs no fill at all -- that fill's central-difference sums, kept per 1024-node block, ARE the
+    // epoch's partials (k_control replays the reference's in-order double accumulation from them).  altValid: the
+    // minus / plus planes hold the sums of the fill at distance altDist; altSel: the coming epoch reads plane 1 / 2
+    int32_t altValid, altDist, altSel;
     int32_t zeroRun;         // grown branches that ended on an evaluated "keep" code: the reference would rewrite that
                              // run of zeros to 3s (R.cpp:662-669,686-688).  Provably never happens for tolerance >= 0
                              // (the last distance is 1), so the emitters do not implement the rewrite; they count here

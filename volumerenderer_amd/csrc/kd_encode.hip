@@ -334,6 +334,7 @@ __global__ void k_ctrl_init(Ctrl *ctrls, const uint8_t *rootMin, const uint8_t *
     c.epoch = 0; c.active = 0; c.fillThisEpoch = 0;
     c.cur = 0; c.prev = 1; c.pendingEqual = 0;
     c.par = 0; c.ra = 1; c.rb = 2;
+    c.altValid = 0; c.altSel = 0; c.altDist = 0;
     c.numReverts = 0; c.maxErrBefore = 0; c.maxErrAfter = 0;
     c.estS = 0; c.estC = 0; c.estTbase = 0; c.estFallbacks = 0; c.estSeg = 0; c.estDone = 0; c.emitOverflow = 0;
     for (int i = 0; i < VR_MAX_DEPTH + 8; ++i) c.distanceMap[i] = 0;
@@ -737,7 +738,7 @@ template <bool STORE>     // false (the leaf level of a leafless build): errors 
 __global__ void __launch_bounds__(256)
 k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
          int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk,
-         SkipBlocks sk)
+         SkipBlocks sk, int64_t errPlane)
 {
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
@@ -747,6 +748,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     const int cConst = c.constBrick, cFill = c.fillThisEpoch, cPar = c.par, cCur = c.cur, cRa = c.ra, cRb = c.rb, cEpoch = c.epoch;
     const double cDist = c.currentDistance;
     if (cConst || !cFill) return;
+    if (!STORE && c.altSel) return;          // this epoch's partials exist already (Ctrl::altSel)
     const uint8_t *T = temp + (int64_t)brick * heapStride + ((int64_t)1 << d);
     uint8_t *Cd = codes + (int64_t)brick * codeStride + ((int64_t)1 << (d - 2));   // packed: 4 codes per byte
     const int rPhys = cCur == 0 ? cRa : cRb;                                         // phys_buf(c, c.cur)
@@ -813,6 +815,10 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         blockErr[(int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = s0;   // 1024 nodes per wave
+        if (!STORE && needDF) {     // the central difference's sums per block too: a following epoch at distance -1 / +1 is these
+            blockErr[errPlane + (int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = sm;
+            blockErr[2 * errPlane + (int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = sp;
+        }
         shm[w] = sm; shp[w] = sp;
     }
     __syncthreads();
@@ -959,7 +965,8 @@ __device__ inline double ctl_partials64(double s, const unsigned long long *__re
 
 __global__ void __launch_bounds__(64)
 k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t heapStride,
-          ReconBufs rb, int64_t leafStride, const unsigned long long *__restrict__ blockErr, int64_t nErrBlk)
+          ReconBufs rb, int64_t leafStride, const unsigned long long *__restrict__ blockErr, int64_t nErrBlk, int64_t errPlane,
+          int leaflessLeaf)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
     Ctrl &c = ctrls[brick];
@@ -972,7 +979,7 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
         const uint8_t *P = rb.b[c.par] + (int64_t)brick * leafStride;
         const int dist = (int)(uint8_t)c.currentDistance;
         const uint32_t nblk = (n + FILL_NODES_PER_BLOCK - 1) / FILL_NODES_PER_BLOCK;
-        const unsigned long long *be = blockErr + (int64_t)brick * nErrBlk;
+        const unsigned long long *be = blockErr + (int64_t)c.altSel * errPlane + (int64_t)brick * nErrBlk;
         // Two levels: every lane sums one chunk of 64 partials (64 independent loads, no dependent steps), the wave
         // adds whole chunks in order while the running double provably stays inside its binade, and only a chunk in
         // which it crosses a power of two is opened (ctl_partials64, which opens only the crossing block).  A level
@@ -1015,6 +1022,10 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
     if (ending) {
         c.roleDist[c.cur] = (int)(uint8_t)c.currentDistance;   // what this epoch's fill wrote its buffer and the codes with
         c.codesDist = (int)(uint8_t)c.currentDistance;
+        // (a real fill that made the central difference leaves its minus / plus partials behind)
+        c.altValid = leaflessLeaf && !c.altSel && c.epoch + 1 < maxEpochs;
+        c.altDist = (int)(uint8_t)c.currentDistance;
+        c.altSel = 0;
         c.currentError = s / (double)n;                        // R.cpp:315
         if (c.currentError < 1.0) {                            // R.cpp:319
             c.active = 0;
@@ -1057,6 +1068,13 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
     c.fillThisEpoch = c.active;
     c.errMinus = c.errPlus = 0;
     if (c.active) c.pendingEqual = 0; // the coming fill overwrites the non-snapshot buffer
+    // the coming epoch is the last that can run (no central difference of its own) and sits one step beside the fill
+    // whose partials are in memory: no fill
+    if (leaflessLeaf && c.active && c.altValid && c.epoch + 1 >= maxEpochs) {
+        const int nd = (int)(uint8_t)c.currentDistance;
+        const int dm = (int)(uint8_t)fmax(0.0, (double)c.altDist - 1.0), dp = (int)(uint8_t)fmin(255.0, (double)c.altDist + 1.0);   // k_fill16's distM / distP
+        if (nd != c.altDist) c.altSel = nd == dm ? 1 : (nd == dp ? 2 : 0);
+    }
 }
 
 // R.cpp:369-381: record the level's distance, make its reconstruction the next level's parents.
@@ -1077,6 +1095,7 @@ __global__ void k_level_end(int d, Ctrl *ctrls)
     c.rb = otherPhys;
     c.cur = 0; c.prev = 1; c.pendingEqual = 0;
     c.active = 0; c.fillThisEpoch = 0;
+    c.altValid = 0; c.altSel = 0;
 }
 
 // The range stream's prune follows the mid stream (M.cpp:864-865); see k_prune_*.
@@ -2685,6 +2704,7 @@ static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uin
     s.ctrl = s0.ctrl + b0; s.temp = s0.temp + (int64_t)b0 * bs->heapStride; s.codes = s0.codes + (int64_t)b0 * bs->codeStride;
     for (int i = 0; i < 3; ++i) s.recon[i] = s0.recon[i] + (int64_t)b0 * bs->reconStride;
     blockErr += (int64_t)b0 * bs->nErrBlk;
+    const int64_t errPlane = (int64_t)bs->B * bs->nErrBlk;     // the minus / plus planes of the partials (leafless leaf level) lie behind the first
     void *estSumm = (uint32_t *)estSumm0 + (int64_t)b0 * bs->estSummStride * (4 * EST_CAND);
     if (sk.flag) sk.flag += (int64_t)b0 * sk.nBlk;
     if (rootMin) { rootMin += (int64_t)b0 * mmStride; rootMax += (int64_t)b0 * mmStride; }
@@ -2715,12 +2735,12 @@ static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uin
             if (n >= 4096)
                 hipLaunchKernelGGL((bs->leafless && d == D) ? k_fill16<false> : k_fill16<true>, dim3((unsigned)(n / 4096), B), dim3(256), 0, st,
                                    d, bs->maxEpochs, s.ctrl, s.temp, s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr,
-                                   bs->nErrBlk, sk);
+                                   bs->nErrBlk, sk, errPlane);
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
                                    s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr, bs->nErrBlk);
             hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, d, bs->maxEpochs, guarded, s.ctrl, s.temp,
-                               bs->heapStride, rb, bs->reconStride, blockErr, bs->nErrBlk);
+                               bs->heapStride, rb, bs->reconStride, blockErr, bs->nErrBlk, errPlane, (bs->leafless && d == D) ? 1 : 0);
         }
         hipLaunchKernelGGL(k_level_end, dim3(B), dim3(64), 0, st, d, s.ctrl);
     }
