@@ -1204,6 +1204,7 @@ k_decode_quad(TileArgs a)
 #define RG_REGX (16 * RG_WAVES)
 #define RG_BLK_WORDS 1028
 #define RG_RING_MASK (RG_NP * 256 - 1)
+static_assert(RG_NP >= 4 && (RG_NP & (RG_NP - 1)) == 0, "the side-cars of the next region are staged in ring slots 2 and 3: at least four pieces, a power of two");
 
 struct RegionArgs {
     const uint8_t *tree;
