@@ -2422,20 +2422,34 @@ k_emit4(EmitArgs a)
 // The decode index of a fused build: block-local offsets -> offsets into the gapped stream buffer (slot b starts at
 // token b * PE_TOKENS), the scalar decoded down to depth Ds, and the scalars of the eight depth-(D-3) nodes below it
 // (k_decode_quad).  Codes under a pruned node are all 3, so the walks are the same for live and dead entries.
-__global__ void __launch_bounds__(64)
-k_index12(EmitArgs a)
-{
-    const int brick = blockIdx.y, t = threadIdx.x, D = a.D;
+__global__ void __launch_bounds__(256)
+k_index12(EmitArgs a, uint32_t nblk)
+{   // a wave per block, four per workgroup (one-wave workgroups: two million of them were dispatch-bound)
+    const int brick = blockIdx.y, t = threadIdx.x & 63, D = a.D;
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (blk >= nblk) return;
     const int64_t bo = (int64_t)brick * a.nEmitBlk + blk;
     const int bflags = a.blockAlive[bo];
     const int bval = a.blockVal[bo];
     const uint32_t s = (blk << 6) + (uint32_t)t;                        // my depth-Ds (= D-6) subtree
     const int64_t io = (int64_t)brick * a.nIdx + s;
-    const uint32_t local = a.idxOff[io];
     const uint8_t *Cb = a.codes + (int64_t)brick * a.codeStride;
+    {   // a block whose root is a pruned token (two thirds of the bench volume's: constant regions), or that lies under
+        // one: every code below moves nothing (3s, or the "keep"s the level loop left under a root k_prune_emit12
+        // pruned), so all 64 entries are dead with the scalar above the block -- one byte decides, nothing else is read
+        const int64_t nr = ((int64_t)1 << (D - 12)) + blk;
+        const uint32_t rootCode = ((uint32_t)Cb[nr >> 2] >> ((int)(nr & 3) * 2)) & 3u;
+        if (rootCode == 3u || !(bflags & 2)) {
+            a.idxOff[io] = VR_IDX_DEAD;
+            if (a.idxBase && t == 0) a.idxBase[bo] = (unsigned long long)blk * PE_TOKENS;
+            a.idxVal[io] = (uint8_t)bval;
+            *(uint2 *)(a.idxVal3 + io * 8) = make_uint2((uint32_t)bval * 0x01010101u, (uint32_t)bval * 0x01010101u);
+            return;
+        }
+    }
+    const uint32_t local = a.idxOff[io];
     uint32_t cb[7];
     int csh[7], dist[7];
 #pragma unroll
@@ -2486,6 +2500,9 @@ k_index12(EmitArgs a)
 // piece's very first and last word can belong to a neighbouring workgroup too: those were zeroed by k_emit_zero and
 // take atomicOr (two atomics per workgroup instead of two per block: the atomics were a third of this kernel).
 #define CC_BLOCKS 16
+#ifndef CC_BATCH
+#define CC_BATCH 4          // chunks per thread whose loads are in flight together
+#endif
 template <bool RANGE>        // RANGE: MidRangeTree's second stream -- same offsets and shape, its own strings and spine
 __global__ void __launch_bounds__(256)
 k_concat12(EmitArgs a, const uint8_t *__restrict__ gap, int64_t nblk)
@@ -2494,6 +2511,8 @@ k_concat12(EmitArgs a, const uint8_t *__restrict__ gap, int64_t nblk)
     __shared__ uint32_t totS[CC_BLOCKS], cntS[CC_BLOCKS];
     __shared__ unsigned long long bwIdx[2 * CC_BLOCKS];     // boundary words: destination word index (~0: unused slot) ...
     __shared__ uint32_t bwVal[2 * CC_BLOCKS];               // ... and this block's bits of it
+    __shared__ uint32_t chunkPre[CC_BLOCKS + 1];            // long blocks: first chunk of every block in the workgroup's chunk list
+    __shared__ uint8_t chunkBlk[CC_BLOCKS * (PE_WORDS / 4 + 4)];   // ... and the block of every chunk
     const int brick = blockIdx.y, t = threadIdx.x;
     Ctrl &c = a.ctrls[brick];
     if (c.constBrick) return;
@@ -2541,50 +2560,86 @@ k_concat12(EmitArgs a, const uint8_t *__restrict__ gap, int64_t nblk)
         if (wl == w0 + 1) { bwIdx[2 * t + 1] = wl; bwVal[2 * t + 1] = x1; }
         else if (wl == w0 + 2) { G0[w0 + 1] = x1; bwIdx[2 * t + 1] = wl; bwVal[2 * t + 1] = x2; }
     }
-    // ---- long blocks: all threads, four destination words per thread and trip
-    for (int i = 0; i < CC_BLOCKS; ++i) {
-        const uint32_t tot = totS[i];
-        if (tot <= 32u) continue;
-        const unsigned long long g0 = g0S[i];
-        const uint32_t cnt = cntS[i];
-        const int nsp = (int)(spineS[i] >> 56);
-        const unsigned long long spine = spineS[i] & 0x00FFFFFFFFFFFFFFull;
-        const int nws = (int)((cnt + 15u) >> 4);
-        const uint32_t *slot = (const uint32_t *)(gap + (int64_t)brick * a.treeCap) + (size_t)(blk0 + i) * PE_WORDS;
-        const uint64_t w0 = g0 >> 4, wl = (g0 + tot - 1) >> 4;
-        const uint64_t wA = w0 & ~3ull;                                  // first destination word of chunk 0 (16-byte aligned)
-        const int nchunk = (int)((wl - wA) / 4 + 1);
-        // bit offset of word wA in the block's string (negative: in front of it)
-        const long long soA = 2ll * ((long long)(16ull * wA) - (long long)g0 - nsp);
-        for (int q = t; q < nchunk; q += 256) {
-            const uint64_t d0 = wA + 4ull * (uint64_t)q;                   // my four destination words d0 .. d0+3
-            const long long so = soA + 128ll * q;
+    // ---- long blocks: their 16-byte destination chunks as ONE list over the workgroup's blocks (a prefix over the
+    // blocks' chunk counts, a byte per chunk saying whose it is), four chunks per thread and trip with all their loads
+    // issued before the first is used: a thread looping over the blocks one after another had one load in flight and
+    // sixteen dependent round trips (2.3 ms for the bench volume's 4.5 GB; the copy itself is 1.6)
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < CC_BLOCKS; ++i) {
+            chunkPre[i] = run;
+            if (totS[i] > 32u) {
+                const uint64_t w0 = g0S[i] >> 4, wl = (g0S[i] + totS[i] - 1) >> 4;
+                run += (uint32_t)((wl - (w0 & ~3ull)) / 4 + 1);
+            }
+        }
+        chunkPre[CC_BLOCKS] = run;
+    }
+    __syncthreads();
+    const uint32_t nchunkAll = chunkPre[CC_BLOCKS];
+    for (int i = 0; i < CC_BLOCKS; ++i)
+        for (uint32_t j = chunkPre[i] + (uint32_t)t; j < chunkPre[i + 1]; j += 256u) chunkBlk[j] = (uint8_t)i;
+    __syncthreads();
+    const uint32_t *gapW = (const uint32_t *)(gap + (int64_t)brick * a.treeCap) + (size_t)blk0 * PE_WORDS;
+    for (uint32_t j0 = (uint32_t)t; j0 < nchunkAll; j0 += 256u * CC_BATCH) {
+        uint32_t sv[CC_BATCH][5];
+        // -- the loads of up to CC_BATCH chunks
+#pragma unroll
+        for (int k = 0; k < CC_BATCH; ++k) {
+            const uint32_t j = j0 + 256u * (uint32_t)k;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) sv[k][m] = 0u;
+            if (j >= nchunkAll) continue;
+            const int i = chunkBlk[j];
+            const unsigned long long g0 = g0S[i];
+            const uint32_t cnt = cntS[i];
+            const int nsp = (int)(spineS[i] >> 56);
+            const int nws = (int)((cnt + 15u) >> 4);
+            const uint32_t *slot = gapW + (size_t)i * PE_WORDS;
+            const uint64_t wA = (g0 >> 4) & ~3ull;
+            const long long so = 2ll * ((long long)(16ull * wA) - (long long)g0 - nsp) + 128ll * (long long)(j - chunkPre[i]);
             const int sw = (int)(so >> 5);                                 // (floor division)
-            const uint32_t shf = (uint32_t)(so & 31ll);
-            uint32_t sv[5];
             if (cnt && sw >= 0 && sw + 4 < nws) {                          // the common case: five words inside the string
                 struct __attribute__((packed, aligned(4))) U4 { uint32_t x, y, z, w; };
                 const U4 u = *(const U4 *)(slot + sw);
-                sv[0] = u.x; sv[1] = u.y; sv[2] = u.z; sv[3] = u.w; sv[4] = slot[sw + 4];
+                sv[k][0] = u.x; sv[k][1] = u.y; sv[k][2] = u.z; sv[k][3] = u.w; sv[k][4] = slot[sw + 4];
             } else {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) sv[k] = (cnt && sw + k >= 0 && sw + k < nws) ? slot[sw + k] : 0u;
+                for (int m = 0; m < 5; ++m) sv[k][m] = (cnt && sw + m >= 0 && sw + m < nws) ? slot[sw + m] : 0u;
             }
+        }
+        // -- shift, edges, store
+#pragma unroll
+        for (int k = 0; k < CC_BATCH; ++k) {
+            const uint32_t j = j0 + 256u * (uint32_t)k;
+            if (j >= nchunkAll) continue;
+            const int i = chunkBlk[j];
+            const unsigned long long g0 = g0S[i];
+            const uint32_t tot = totS[i], cnt = cntS[i];
+            const int nsp = (int)(spineS[i] >> 56);
+            const unsigned long long spine = spineS[i] & 0x00FFFFFFFFFFFFFFull;
+            const uint64_t w0 = g0 >> 4, wl = (g0 + tot - 1) >> 4;
+            const uint64_t wA = w0 & ~3ull;                                  // first destination word of chunk 0 (16-byte aligned)
+            const uint32_t q = j - chunkPre[i];
+            const uint64_t d0 = wA + 4ull * (uint64_t)q;                     // my four destination words d0 .. d0+3
+            // bit offset of word d0 in the block's string (negative: in front of it)
+            const long long so = 2ll * ((long long)(16ull * wA) - (long long)g0 - nsp) + 128ll * (long long)q;
+            const uint32_t shf = (uint32_t)(so & 31ll);
             uint32_t o[4];
             const int tok0 = (int)(so >> 1);                               // string token at bit 0 of word d0
             const bool edge = tok0 < 0 || tok0 + 64 > (int)cnt;            // the chunk touches the string's start or end
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                o[k] = __builtin_amdgcn_alignbit(sv[k + 1], sv[k], shf);
+            for (int m = 0; m < 4; ++m) {
+                o[m] = __builtin_amdgcn_alignbit(sv[k][m + 1], sv[k][m], shf);
                 if (edge) {
-                    const int tokAt = tok0 + 16 * k;
+                    const int tokAt = tok0 + 16 * m;
                     if (tokAt + 16 > (int)cnt) {        // the string's last word may carry stale bits behind the last token: cut them
                         const int keep = (int)cnt - tokAt;
-                        o[k] = keep <= 0 ? 0u : (keep >= 16 ? o[k] : (o[k] & ((1u << (2 * keep)) - 1u)));
+                        o[m] = keep <= 0 ? 0u : (keep >= 16 ? o[m] : (o[m] & ((1u << (2 * keep)) - 1u)));
                     }
                     if (tokAt < 0 && nsp) {             // in front of the string: the spine's bits
-                        const long long bo2 = 2ll * ((long long)(16ull * (d0 + k)) - (long long)g0);
-                        o[k] |= bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
+                        const long long bo2 = 2ll * ((long long)(16ull * (d0 + m)) - (long long)g0);
+                        o[m] |= bo2 >= 0 ? (bo2 < 64 ? (uint32_t)(spine >> bo2) : 0u) : (uint32_t)(spine << (-bo2));
                     }
                 }
             }
@@ -2592,12 +2647,12 @@ k_concat12(EmitArgs a, const uint8_t *__restrict__ gap, int64_t nblk)
                 *(uint4 *)(G0 + d0) = make_uint4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint64_t d = d0 + k;
+                for (int m = 0; m < 4; ++m) {
+                    const uint64_t d = d0 + m;
                     if (d < w0 || d > wl) continue;
-                    if (d == w0) { bwIdx[2 * i] = d; bwVal[2 * i] = o[k]; }
-                    else if (d == wl) { bwIdx[2 * i + 1] = d; bwVal[2 * i + 1] = o[k]; }
-                    else G0[d] = o[k];
+                    if (d == w0) { bwIdx[2 * i] = d; bwVal[2 * i] = o[m]; }
+                    else if (d == wl) { bwIdx[2 * i + 1] = d; bwVal[2 * i + 1] = o[m]; }
+                    else G0[d] = o[m];
                 }
             }
         }
@@ -3024,7 +3079,7 @@ int encode_launch(BrickSet *bs, const uint8_t *vox, hipStream_t st)
     // contiguous stream is made when the host asks for it (compact_launch)
     bs->gapped = fused;
     bs->compactValid = false;
-    if (fused) hipLaunchKernelGGL(k_index12, dim3((unsigned)nblk, B), dim3(64), 0, st, a);
+    if (fused) hipLaunchKernelGGL(k_index12, dim3(cdiv(nblk, 4), B), dim3(256), 0, st, a, (uint32_t)nblk);
     else {
         hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
         if (quad) hipLaunchKernelGGL(k_emit4<true>, dim3((unsigned)nblk, B), dim3(256), 0, st, a);
