@@ -734,12 +734,19 @@ __device__ __forceinline__ void leaf_pair_encode(uint32_t tword, int tsel, uint3
     codes2 = take & pk_u(pk_s(c.up) + pk_s(0x00020002u));                   // up ? 1 : 2 (per-lane wrap)
 }
 
+#ifndef FILL_ITERS
+#define FILL_ITERS 8        // chunks of 4096 nodes per workgroup of k_fill16 (large levels)
+#endif
 template <bool STORE>     // false (the leaf level of a leafless build): errors only -- k_prune_emit12 recomputes codes and reconstruction
 __global__ void __launch_bounds__(256)
 k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, uint8_t *__restrict__ codes, int64_t heapStride,
          int64_t codeStride, ReconBufs rb, int64_t leafStride, unsigned long long *__restrict__ blockErr, int64_t nErrBlk,
-         SkipBlocks sk, int64_t errPlane)
+         SkipBlocks sk, int64_t errPlane, int iters)
 {
+    // A workgroup takes `iters` consecutive chunks of 4096 nodes (a wave: 1024 = one partial-sum block of k_control),
+    // the next chunk's loads in flight while this one is evaluated: two million four-wave workgroups at the leaf level
+    // spent a third of the launch being dispatched and reading the control block (a level-D fill in which every wave
+    // skipped took 0.94 ms).
     __shared__ unsigned long long shm[4], shp[4];
     const int brick = blockIdx.y;
     // everything the wave needs from the brick's control block is fetched in ONE scalar round trip, before the
@@ -760,14 +767,28 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     // the central difference (R.cpp:333-362) only steers a FOLLOWING epoch: in the last one its result is
     // never read (VolumeKdtree.cpp:333 skips it outright), so the two extra evaluations are not made
     const bool needDF = cEpoch + 1 < maxEpochs;
-    const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 16u;
-    // my wave's 1024 nodes inside a skipped block (SkipBlocks): no error, nothing to load, nothing anybody will read
-    const bool skipped = skip_block(sk, brick, d, (uint32_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) << 10);
-    uint4 tv = make_uint4(0, 0, 0, 0);
-    uint2 pv = make_uint2(0, 0);
-    if (!skipped) { tv = ld16(T + i0); pv = ld8(P + (i0 >> 1)); }
-    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
     const uint32_t d2 = (uint32_t)dist * 0x10001u, dm2 = (uint32_t)distM * 0x10001u, dp2 = (uint32_t)distP * 0x10001u;
+    const int w = threadIdx.x >> 6;
+    const uint32_t nchunk = (uint32_t)(((size_t)1 << d) >> 12);
+    uint32_t chunk = blockIdx.x * (uint32_t)iters;
+    const uint32_t chunkEnd = chunk + (uint32_t)iters < nchunk ? chunk + (uint32_t)iters : nchunk;
+    unsigned long long accM = 0, accP = 0;
+    // my wave's 1024 nodes inside a skipped block (SkipBlocks): no error, nothing to load, nothing anybody will read
+    bool skippedN = skip_block(sk, brick, d, (chunk * 4u + (uint32_t)w) << 10);
+    uint4 tvN = make_uint4(0, 0, 0, 0);
+    uint2 pvN = make_uint2(0, 0);
+    if (!skippedN) { const size_t i0 = ((size_t)chunk * 256u + threadIdx.x) * 16u; tvN = ld16(T + i0); pvN = ld8(P + (i0 >> 1)); }
+    for (; chunk < chunkEnd; ++chunk) {
+    const size_t i0 = ((size_t)chunk * 256u + threadIdx.x) * 16u;
+    const bool skipped = skippedN;
+    const uint4 tv = tvN;
+    const uint2 pv = pvN;
+    if (chunk + 1 < chunkEnd) {
+        skippedN = skip_block(sk, brick, d, ((chunk + 1u) * 4u + (uint32_t)w) << 10);
+        tvN = make_uint4(0, 0, 0, 0); pvN = make_uint2(0, 0);
+        if (!skippedN) { const size_t i1 = i0 + 4096u; tvN = ld16(T + i1); pvN = ld8(P + (i1 >> 1)); }
+    }
+    const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, pw[2] = {pv.x, pv.y};
     uint32_t e0 = 0, em = 0, ep = 0, wa = 0, wb = 0, rw[4] = {tw[0], tw[1], tw[2], tw[3]}, rprev = 0;
     // a wave whose 1024 truths all equal their parents' reconstruction (constant regions) has nothing to decide:
     // every code is "keep", the reconstruction is the truth, the error 0 at any distance (pd = 0 in encodeNode)
@@ -777,7 +798,7 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
     // level D-2: my wave IS one 4096-leaf block's nodes of this level.  Constant block (k_pyramid12) and every truth
     // equal to its parent's reconstruction: the two levels below need not be visited (SkipBlocks)
     if (sk.flag && d == sk.Dm2 && !busy && (threadIdx.x & 63) == 0) {
-        uint8_t *f = sk.flag + (int64_t)brick * sk.nBlk + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        uint8_t *f = sk.flag + (int64_t)brick * sk.nBlk + (size_t)chunk * 4 + w;
         if (*f & 1u) *f = 3u;        // the same answer in every epoch of the level: it depends on truths and parents only
     }
     if (busy)
@@ -812,15 +833,16 @@ k_fill16(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, ui
         sm = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(em), 63);
         sp = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_dpp(ep), 63);
     }
-    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        blockErr[(int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = s0;   // 1024 nodes per wave
+        blockErr[(int64_t)brick * nErrBlk + (size_t)chunk * 4 + w] = s0;   // 1024 nodes per wave
         if (!STORE && needDF) {     // the central difference's sums per block too: a following epoch at distance -1 / +1 is these
-            blockErr[errPlane + (int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = sm;
-            blockErr[2 * errPlane + (int64_t)brick * nErrBlk + (size_t)blockIdx.x * 4 + w] = sp;
+            blockErr[errPlane + (int64_t)brick * nErrBlk + (size_t)chunk * 4 + w] = sm;
+            blockErr[2 * errPlane + (int64_t)brick * nErrBlk + (size_t)chunk * 4 + w] = sp;
         }
-        shm[w] = sm; shp[w] = sp;
     }
+    accM += sm; accP += sp;
+    }
+    if ((threadIdx.x & 63) == 0) { shm[w] = accM; shp[w] = accP; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long tm = shm[0] + shm[1] + shm[2] + shm[3], tp = shp[0] + shp[1] + shp[2] + shp[3];
@@ -2788,9 +2810,12 @@ static void compress_stream(BrickSet *bs, Stream2 &s0, hipStream_t st, const uin
         }
         for (int e = 0; e < bs->maxEpochs; ++e) {
             if (n >= 4096)
-                hipLaunchKernelGGL((bs->leafless && d == D) ? k_fill16<false> : k_fill16<true>, dim3((unsigned)(n / 4096), B), dim3(256), 0, st,
+            {
+                const int iters = n / 4096 >= 512 ? FILL_ITERS : (n / 4096 >= 64 ? (FILL_ITERS < 4 ? FILL_ITERS : 4) : 1);
+                hipLaunchKernelGGL((bs->leafless && d == D) ? k_fill16<false> : k_fill16<true>, dim3(cdiv(n / 4096, iters), B), dim3(256), 0, st,
                                    d, bs->maxEpochs, s.ctrl, s.temp, s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr,
-                                   bs->nErrBlk, sk, errPlane);
+                                   bs->nErrBlk, sk, errPlane, iters);
+            }
             else
                 hipLaunchKernelGGL(k_fill, dim3(cdiv(n, FILL_NODES_PER_BLOCK), B), dim3(256), 0, st, d, s.ctrl, s.temp,
                                    s.codes, bs->heapStride, bs->codeStride, rb, bs->reconStride, blockErr, bs->nErrBlk);
