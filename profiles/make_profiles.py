@@ -31,8 +31,9 @@ nbuild = kern["vr::k_pyramid12"]["launches"]
 enc = 0
 enc_by_kernel = {}
 for k, e in kern.items():
-    if k in (dk, "vr::k_raycast", "vr::k_assemble", "vr::k_skip_grid8", "vr::k_skip_grid") or k.startswith("vr::k_decode"):
-        continue
+    if any(k.startswith(x) for x in ("vr::k_decode", "vr::k_raycast", "vr::k_assemble", "vr::k_disassemble", "vr::k_skip_grid", "vr::k_composite",
+                                     "vr::k_measure", "vr::k_query")):
+        continue            # (not part of a build)
     b = (2 * e.get("FETCH_SIZE_KiB_per_launch_avg", 0.0) + e.get("WRITE_SIZE_KiB_per_launch_avg", 0.0)) * 1024 * e["launches"] / nbuild
     enc_by_kernel[k] = int(b)
     enc += b
