@@ -528,6 +528,15 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         if (lane < 4 * nc) out[est_at(lane >> 2, seg) + (lane & 3)] = 0;
         continue;
     }
+    // every h of the wave at or above the last candidate (the usual case away from 0 and 255): min(Th, h) = Th
+    vr_s16x2 hmin = h[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) hmin = __builtin_elementwise_min(hmin, h[k]);
+#ifdef EST_NO_HBIG          // (timing experiments)
+    const bool hBig = false;
+#else
+    const bool hBig = __ballot(min((int)hmin.x, (int)hmin.y) < Tbase + nc - 1) == 0ull;
+#endif
 #pragma unroll 1
     for (int ci = 0; ci < nc; ++ci) {
         const int Th = Tbase + ci;
@@ -535,6 +544,18 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         // per chain: low = 2*Th*cc - s, and the extremes of low / low + 2cc over the positions BEFORE each node
         vr_s16x2 low = (vr_s16x2)(0), cc = (vr_s16x2)(0), amax = (vr_s16x2)(0), bmin = (vr_s16x2)(0);
         const vr_s16x2 two2 = pk_s(0x00020002u);
+        if (hBig) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const vr_s16x2 dm = (Th2 - pd[k]) >> 15;     // -1 where the node counts
+            low = dm * (pd[k] - w2) + low;
+            cc -= dm;
+            if (k < 7) {
+                amax = __builtin_elementwise_max(amax, low);
+                bmin = __builtin_elementwise_min(bmin, pk_mad(cc, two2, low));
+            }
+        }
+        } else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const vr_s16x2 dm = (__builtin_elementwise_min(Th2, h[k]) - pd[k]) >> 15;     // -1 where the node counts
