@@ -1514,7 +1514,7 @@ k_decode_region(RegionArgs a)
     stage(rid, 0);
     int slot = 0;           // index slot of the current region
 #ifdef RG_STAMP             // (diagnostic build: where a wave's cycles go; never timed)
-    unsigned long long tAcc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tAcc[6] = {0, 0, 0, 0, 0, 0}, tPiece = 0;
 #define RG_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tAcc[i] += now_ - tLast; tLast = now_; } while (0)
     unsigned long long tLast = __builtin_amdgcn_s_memtime();
     const unsigned long long tStart = tLast;
@@ -1568,7 +1568,13 @@ k_decode_region(RegionArgs a)
                 // the pieces this trip reads must have landed
                 const uint32_t need = (((endTok + 15u) >> 4) + 255u) >> 8;
                 if (need > landed) {
+#ifdef RG_STAMP
+                    const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
                     rg_vm_wait(ops - mark_of_piece(need - 1u));
+#ifdef RG_STAMP
+                    tPiece += __builtin_amdgcn_s_memtime() - w0_;
+#endif
                     landed = need;
                     while (guardNext < need) {     // a piece has landed on the ring's first slot: its first four words again behind the last slot
                         if (lane < 4) ringW[RG_NP * 256 + lane] = ringW[lane];
@@ -1682,6 +1688,7 @@ k_decode_region(RegionArgs a)
         atomicAdd(&a.dbg[0], __builtin_amdgcn_s_memtime() - tStart);
         for (int i = 1; i < 6; ++i) atomicAdd(&a.dbg[i], tAcc[i]);
         atomicAdd(&a.dbg[6], 1ull);
+        atomicAdd(&a.dbg[7], tPiece);
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (no LDS-DMA may outlive the workgroup's LDS)
@@ -1902,8 +1909,8 @@ int decode_launch(BrickSet *bs, uint8_t *out, int cut, hipStream_t st, bool rang
                 if (!dbgDev) { hipMalloc(&dbgDev, 64); hipMemset(dbgDev, 0, 64); }
                 unsigned long long h[8];
                 hipMemcpy(h, dbgDev, 64, hipMemcpyDeviceToHost);
-                if (h[6]) fprintf(stderr, "[rg stamp] waves %llu  cycles/wave: total %.0f park %.0f steps+stage %.0f barrier1 %.0f gather %.0f barrier2+top %.0f\n", h[6],
-                                  (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+                if (h[6]) fprintf(stderr, "[rg stamp] waves %llu  cycles/wave: total %.0f park %.0f steps+stage %.0f (of it waiting for string pieces %.0f) barrier1 %.0f gather %.0f barrier2+top %.0f\n", h[6],
+                                  (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[7] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
                 hipMemset(dbgDev, 0, 64);
                 r.dbg = dbgDev;
             }
