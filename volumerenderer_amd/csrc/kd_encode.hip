@@ -1693,8 +1693,6 @@ k_prune_emit12(PruneEmitArgs a)
                (tv.z ^ __builtin_amdgcn_perm(0, pv.y, 0x01010000u)) | (tv.w ^ __builtin_amdgcn_perm(0, pv.y, 0x03030202u))) != 0u ? 1u : 0u;
     }
     lutS[t] = lutV; lutS[256 + t] = lutV2;
-    { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
-    for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
     // ---- a block of 4096 exactly reproduced leaves under all-"keep" codes (constant regions) is one pruned subtree:
     // its string is the single token 3, its index entries are "pruned", its statistics zero.  Only the root's code
     // is written back: nothing reads the codes below a pruned node for anything but their (equal) scalars.
@@ -1720,6 +1718,10 @@ k_prune_emit12(PruneEmitArgs a)
         if (t < 64) a.idxOff[(int64_t)brick * a.nIdx + (base >> 6) + t] = VR_IDX_DEAD;
         return;
     }
+    // (the string buffer and the upper codes: only blocks that get here need them -- two thirds leave above -- and
+    // barriers lie between these stores and their first readers)
+    { const uint8_t cu = (uint8_t)((upB >> ((int)(niU & 3) * 2)) & 3u); codeH[t] = cu; codeOldH[t] = cu; }
+    for (int i = t; i < PE_WORDS; i += 256) W[i] = 0;
     // ---- leaves: prune (R.cpp:618-626), grown branches (R.cpp:655-704); sibling leaves share packed 16-bit lanes
     const uint32_t tw[4] = {tv.x, tv.y, tv.z, tv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w}, pwL[2] = {pv.x, pv.y};
     const uint32_t dR2 = (uint32_t)cDistR * 0x10001u, dC2 = (uint32_t)cDistC * 0x10001u;
@@ -1730,7 +1732,11 @@ k_prune_emit12(PruneEmitArgs a)
     const int nsteps = a.maxDepth - D;    // distanceMap[D+1..] = 64, 32, .., 1 (R.cpp:23,94-97)
     // a wave whose 1024 leaves all carry code 0 and are reproduced exactly (constant regions) prunes them all:
     // one '3' per leaf, no branches, no statistics to add
+#ifdef PE_KO_LEAF
+    const bool busy = false;
+#else
     const bool busy = __ballot(!plain) != 0ull;
+#endif
     if (!busy) {
         bothMask = 0x5555u;
 #pragma unroll
@@ -1774,13 +1780,18 @@ k_prune_emit12(PruneEmitArgs a)
             act[jj] = ~pruned & viol;
             anyAct |= act[jj];
         }
+#ifdef PE_KO_STEP
+        for (int i = 0; i < 0; ++i) {
+#else
         for (int i = 0; i < nsteps; ++i) {    // exact stepping for the leaves the table does not cover
+#endif
             if (__ballot(anyAct != 0) == 0ull) break;
             const uint32_t d2 = (uint32_t)(64 >> i) * 0x10001u;
             anyAct = 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int j = half * 4 + jj;
+                if (__ballot(act[jj] != 0u) == 0ull) continue;     // such leaves are rare: usually one pair slot of the wave at most
                 const vr_s16x2 mm = pk_s(m[jj]);
                 const uint32_t gt = pk_u((pk_s(tol2) - mm) >> 15);
                 nt[j] = pk_u(pk_s(nt[j]) - pk_s(act[jj]));
@@ -1958,7 +1969,11 @@ k_prune_emit12(PruneEmitArgs a)
     uint32_t bitpos = 2u * pos;
     pe_put(W, bitpos, (unsigned long long)S, ns);
     bitpos += 2u * (uint32_t)ns;
+#ifdef PE_KO_COMPOSE
+    if (false) {
+#else
     if (alive) {
+#endif
         // preorder of my 31-node subtree; internal tokens wait in (pb, pn) and leave with the next leaf-pair piece
         unsigned long long pb = a4;
         int pn = 1;
@@ -2014,7 +2029,11 @@ k_prune_emit12(PruneEmitArgs a)
     // build sits right behind it (the decoders fetch whole words past a run's end; what they fetch there is never used)
     const uint32_t nw = min((tot + 15u) / 16u + 1u, (uint32_t)PE_WORDS);
     uint32_t *slot = (uint32_t *)((RANGE ? a.gapR : a.gap) + (int64_t)brick * a.treeCap) + (size_t)blk * PE_WORDS;
+#ifndef PE_KO_COPY
     for (uint32_t i = t; i < nw; i += 256u) slot[i] = W[i];
+#else
+    if (t == 0) slot[0] = W[0] + nw;
+#endif
 }
 
 
