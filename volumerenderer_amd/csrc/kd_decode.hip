@@ -1090,8 +1090,13 @@ k_decode_quad(TileArgs a)
             const bool stepDead = ((uint32_t)(liveMask >> (lane & 60)) & 15u) == 0u;     // my step's four blocks are all dead
             const uint32_t deadW = stepDead ? rep : val0;
             uint32_t run = 0;
+#ifdef RG_KO_PARK           // (timing experiments)
+#pragma unroll
+            for (int gg = 0; gg < 1; ++gg) {
+#else
 #pragma unroll
             for (int gg = 0; gg < 16; ++gg) {
+#endif
                 const uint32_t cgg = (cw[gg >> 2] >> (8 * (gg & 3))) & 255u;
                 const int own = gg == 0 ? 4 : (gg & 1 ? 0 : (gg & 2 ? 1 : (gg & 4 ? 2 : 3)));
                 const uint32_t vgg = (sw[gg >> 3] >> (8 * ((gg >> 1) & 3))) & 255u;
@@ -1543,8 +1548,13 @@ k_decode_region(RegionArgs a)
             const bool stepDead = ((uint32_t)(liveMask >> (lane & 60)) & 15u) == 0u;
             const uint32_t deadW = stepDead ? valC * 0x01010101u : valC;
             uint32_t run = liveL ? offC - wbase * 16u : 0u;
+#ifdef RG_KO_PARK           // (timing experiments)
+#pragma unroll
+            for (int gg = 0; gg < 1; ++gg) {
+#else
 #pragma unroll
             for (int gg = 0; gg < 16; ++gg) {
+#endif
                 const uint32_t cgg = (cw[gg >> 2] >> (8 * (gg & 3))) & 255u;
                 const int own = gg == 0 ? 4 : (gg & 1 ? 0 : (gg & 2 ? 1 : (gg & 4 ? 2 : 3)));
                 const uint32_t vgg = (sw2[gg >> 3] >> (8 * ((gg >> 1) & 3))) & 255u;
@@ -1618,6 +1628,9 @@ k_decode_region(RegionArgs a)
         RG_T(3);
         // ---- gather: a 16-byte row piece of emit block c = lane & 7 per lane, eight whole 128-byte lines per store.
         // All reads of the image first (they are independent), then the byte picks and the stores.
+#ifdef RG_KO_GATHER         // (timing experiments)
+        if (false)
+#endif
         {
             const uint32_t *img = sm.buf + (lane & (RG_WAVES - 1)) * RG_BLK_WORDS;
             const uint32_t xr1 = a.xRead[0] >> 16, xr2 = a.xRead[1] & 0xFFFFu, xr3 = a.xRead[1] >> 16;
