@@ -2936,8 +2936,9 @@ int compact_launch(BrickSet *bs, hipStream_t st)
     hipLaunchKernelGGL(k_emit_zero, dim3(cdiv(nblk, 256), B), dim3(256), 0, st, a, nblk);
     hipLaunchKernelGGL(k_concat12<false>, dim3(cdiv(nblk, CC_BLOCKS), B), dim3(256), 0, st, a, bs->mid.tree, nblk);
     if (mr) hipLaunchKernelGGL(k_concat12<true>, dim3(cdiv(nblk, CC_BLOCKS), B), dim3(256), 0, st, a, bs->rng.tree, nblk);
-    hipLaunchKernelGGL(k_const_finish, dim3(cdiv(bs->nIdx, 256), B), dim3(256), 0, st, D, bs->mid.ctrl, bs->mid.treeCompact,
-                       bs->treeCap, bs->idxOff, bs->idxVal, bs->nIdx, bs->brickOff, bs->compactCap);
+    // (the closed form's stream word only: its index entries were written when the gapped stream was finished)
+    hipLaunchKernelGGL(k_const_finish, dim3(1, B), dim3(64), 0, st, D, bs->mid.ctrl, bs->mid.treeCompact,
+                       bs->treeCap, bs->idxOff, bs->idxVal, (int64_t)0, bs->brickOff, bs->compactCap);
     if (mr) hipLaunchKernelGGL(k_const_finish_range, dim3(B), dim3(64), 0, st, D, bs->rng.ctrl, bs->rng.treeCompact, bs->treeCap, bs->brickOff, bs->compactCap);
     bs->compactValid = true;
     return launch_status("compact");
