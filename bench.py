@@ -683,68 +683,126 @@ def main():
         # sort-last frames over RCCL (the path's one real exchange): rank r ray-marches ITS slab of the decoded volume
         # (strong: the y-slab of the bricks it decoded, plus one halo plane from each neighbour; weak: z-slab r of its own
         # volume) into a partial (c, tau) image; vr_compositor_composite: direct-send exchange (grouped ncclSend / ncclRecv),
-        # per-pixel ordered combine, gather on rank 0.  A failure here ends the run non-zero (no retry, no re-exec): the
-        # process group's timeout turns a collective that cannot complete into an error.
+        # per-pixel ordered combine, gather on rank 0.  The leg runs in stages; after each, the ranks agree (all-reduce MIN)
+        # that every one of them got through it, so an error that is local to a rank -- out of memory, RCCL not bindable,
+        # a bug -- makes all of them skip the rest and is reported in the line (`composite_error`) instead of leaving the
+        # others in a collective.  A collective that cannot complete is the process group's timeout's business: the run
+        # then ends non-zero (no retry, no re-exec).
         from volumerenderer_amd import distributed as D
         ax = 1 if strong else 2
-        if strong:
-            lo_b, hi_b = my_slab
-            ylo, yhi = lo_b * bdims[1], hi_b * bdims[1]
-            ijk = np.array([[b % grid[0], (b // grid[0]) % grid[1] - lo_b, b // (grid[0] * grid[1])] for b in my_ids], np.int64)
-            slab = vr.assemble_bricks(out, bdims, ijk, (grid[0], hi_b - lo_b, grid[2])).reshape(gdims[2], yhi - ylo, gdims[0])
-            # halo planes: my first plane to the rank below, my last one to the rank above
-            lo_halo = torch.empty((gdims[2], 1, gdims[0]), dtype=torch.uint8, device="cuda") if rank > 0 else None
-            hi_halo = torch.empty((gdims[2], 1, gdims[0]), dtype=torch.uint8, device="cuda") if rank < world - 1 else None
-            first, last = slab[:, :1].contiguous(), slab[:, -1:].contiguous()
-            ops = []
-            if rank > 0:
-                ops += [dist.P2POp(dist.isend, first, rank - 1), dist.P2POp(dist.irecv, lo_halo, rank - 1)]
-            if rank < world - 1:
-                ops += [dist.P2POp(dist.isend, last, rank + 1), dist.P2POp(dist.irecv, hi_halo, rank + 1)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            slab = torch.cat([t_ for t_ in (lo_halo, slab, hi_halo) if t_ is not None], dim=1).contiguous()
-            a0 = ylo - (1 if rank > 0 else 0)
-            sub_dims = (gdims[0], slab.shape[1], gdims[2])
-            lo_f, hi_f, ext = ylo, yhi, gdims[1]
-        else:
+        stage_err = [None]
+
+        def agree(tag, fn):
+            """fn() on every rank, then MIN over the ranks of "it worked": what fn returned, or None if anybody failed"""
+            out_, ok_ = None, 1
+            if stage_err[0] is None:
+                try:
+                    out_ = fn()
+                except Exception as ex:          # noqa: BLE001 -- reported, never swallowed
+                    ok_ = 0
+                    stage_err[0] = "%s: %r" % (tag, ex)
+            else:
+                ok_ = 0
+            flag = torch.tensor([ok_], device="cpu" if rehearsal else "cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and stage_err[0] is None:
+                stage_err[0] = "%s: failed on another rank" % tag
+            return out_ if stage_err[0] is None else None
+
+        def stage_slab():
+            if strong:
+                lo_b, hi_b = my_slab
+                ylo, yhi = lo_b * bdims[1], hi_b * bdims[1]
+                ijk = np.array([[b % grid[0], (b // grid[0]) % grid[1] - lo_b, b // (grid[0] * grid[1])] for b in my_ids], np.int64)
+                slab_ = vr.assemble_bricks(out, bdims, ijk, (grid[0], hi_b - lo_b, grid[2])).reshape(gdims[2], yhi - ylo, gdims[0])
+                return slab_, ylo, yhi
             vol = vr.assemble_bricks(out, bdims, np.array([[b % grid[0], (b // grid[0]) % grid[1], b // (grid[0] * grid[1])]
                                                             for b in range(B)], np.int64), grid)
             zlo, zhi = D.shard_range(gdims[2], rank, world)
-            a0, a1 = max(0, zlo - 1), min(gdims[2], zhi + 1)
-            slab = vol.reshape(gdims[2], gdims[1], gdims[0])[a0:a1].contiguous()
-            del vol
-            sub_dims = (gdims[0], gdims[1], a1 - a0)
-            lo_f, hi_f, ext = zlo, zhi, gdims[2]
+            a0_, a1_ = max(0, zlo - 1), min(gdims[2], zhi + 1)
+            return vol.reshape(gdims[2], gdims[1], gdims[0])[a0_:a1_].contiguous(), zlo, zhi
+
+        got = agree("assemble the slab", stage_slab)
+        slab = sub_dims = None
+        a0 = lo_f = hi_f = ext = 0
+        if got is not None:
+            slab, lo_f, hi_f = got
+            if strong:
+                def stage_halo():
+                    # halo planes: my first plane to the rank below, my last one to the rank above
+                    lo_halo = torch.empty((gdims[2], 1, gdims[0]), dtype=torch.uint8, device="cuda") if rank > 0 else None
+                    hi_halo = torch.empty((gdims[2], 1, gdims[0]), dtype=torch.uint8, device="cuda") if rank < world - 1 else None
+                    first, last = slab[:, :1].contiguous(), slab[:, -1:].contiguous()
+                    ops = []
+                    if rank > 0:
+                        ops += [dist.P2POp(dist.isend, first, rank - 1), dist.P2POp(dist.irecv, lo_halo, rank - 1)]
+                    if rank < world - 1:
+                        ops += [dist.P2POp(dist.isend, last, rank + 1), dist.P2POp(dist.irecv, hi_halo, rank + 1)]
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                    return torch.cat([t_ for t_ in (lo_halo, slab, hi_halo) if t_ is not None], dim=1).contiguous()
+                slab = agree("halo exchange", stage_halo)
+                a0 = lo_f - (1 if rank > 0 else 0)
+                ext = gdims[1]
+                if slab is not None:
+                    sub_dims = (gdims[0], slab.shape[1], gdims[2])
+            else:
+                a0 = max(0, lo_f - 1)
+                ext = gdims[2]
+                sub_dims = (gdims[0], gdims[1], slab.shape[0])
         cam = vr.default_camera()
         P = vr.default_params(1920, 1080, (256, 256, 128), vr.RENDER_PARTIAL)
-        bmin, bmax, org = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 0, 0]
-        bmin[ax] = lo_f / ext
-        bmax[ax] = hi_f / ext if rank < world - 1 else 2.0
-        org[ax] = a0
-        P.box_min[:] = tuple(bmin); P.box_max[:] = tuple(bmax)
-        P.global_dims[:] = gdims
-        P.vol_origin[:] = tuple(org)
-        part = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
-        frame = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+        part = frame = None
+        if stage_err[0] is None:
+            bmin, bmax, org = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0, 0, 0]
+            bmin[ax] = lo_f / ext
+            bmax[ax] = hi_f / ext if rank < world - 1 else 2.0
+            org[ax] = a0
+            P.box_min[:] = tuple(bmin); P.box_max[:] = tuple(bmax)
+            P.global_dims[:] = gdims
+            P.vol_origin[:] = tuple(org)
+
+        def stage_bind():
+            # every rank checks that it can bind RCCL and allocate its images BEFORE any of them enters the communicator's
+            # collective initialisation
+            from volumerenderer_amd import _lib
+            import ctypes as C_
+            probe = (C_.c_uint8 * 128)()
+            _lib.check(_lib.lib().vr_rccl_unique_id(probe), "vr_rccl_unique_id")
+            part_ = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+            frame_ = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+            return part_, frame_
+
+        got = agree("bind RCCL", stage_bind)
+        if got is not None:
+            part, frame = got
         frames = 36
-        for warm in (True, False):
-            torch.cuda.synchronize()
-            dist.barrier()
-            r0 = time.perf_counter()
-            for f in range(frames):
-                th = math.radians(f * 10.0)
-                cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
-                cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
-                vr.raycast(slab.reshape(-1), sub_dims, cam, P, part)
-                D.composite_sort_last(part, cam, P, axis=ax, out=frame)
-            torch.cuda.synchronize()
-            dist.barrier()
-            cfps = frames / (time.perf_counter() - r0)
-        res["composited_1080p_fps"] = round(cfps, 1)
-        res["composite"] = {"axis": "xyz"[ax], "slab_voxels_rank0": [int(v) for v in sub_dims], "exchange": "vr_compositor_composite (C ABI): grouped "
-                            "ncclSend/ncclRecv direct send, k_composite_slabs, gather on rank 0"}
-        if strong and rank == 0:
+
+        def stage_frames():
+            cfps_ = 0.0
+            for warm in (True, False):
+                torch.cuda.synchronize()
+                dist.barrier()
+                r0 = time.perf_counter()
+                for f in range(frames):
+                    th = math.radians(f * 10.0)
+                    cam.pos[:] = (0.75 * math.sin(th), 0.0, -0.75 * math.cos(th))
+                    cam.front[:] = (-math.sin(th), 0.0, math.cos(th))
+                    vr.raycast(slab.reshape(-1), sub_dims, cam, P, part)
+                    D.composite_sort_last(part, cam, P, axis=ax, out=frame)
+                torch.cuda.synchronize()
+                dist.barrier()
+                cfps_ = frames / (time.perf_counter() - r0)
+            return cfps_
+
+        cfps = agree("composited frames", stage_frames)
+        if stage_err[0] is not None:
+            res["composite_error"] = stage_err[0][:300]
+        else:
+            res["composited_1080p_fps"] = round(cfps, 1)
+            res["composite"] = {"axis": "xyz"[ax], "slab_voxels_rank0": [int(v) for v in sub_dims], "exchange": "vr_compositor_composite (C ABI): grouped "
+                                "ncclSend/ncclRecv direct send, k_composite_slabs, gather on rank 0"}
+        if strong and rank == 0 and stage_err[0] is None:
             # the same frame from one GPU: rank 0 decodes the whole volume once more (outside every timed region) and
             # marches it without the early exit the slabs cannot honour (raycaster.frag:76)
             del slab
