@@ -389,9 +389,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the MidRangeTree / config-5 streaming leg")
-    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3],
-                    help="bricksets in flight, each on its own stream with its own output volume.  3 (default, ~65 GB "
-                         "each of the 288 GB): build + levelCut of steps k, k+1, k+2 run beside each other (the streaming "
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3, 4, 6, 8],
+                    help="bricksets in flight, each on its own stream with its own output volume.  0 (default) = 3 (~59 GB "
+                         "each of the 288 GB for a whole volume): build + levelCut of steps k, k+1, k+2 run beside each other (the streaming "
                          "use: the next timesteps compress while this one decodes; falls back to 2 if the third set "
                          "does not fit); 1: strictly serial")
     ap.add_argument("--level-loop-streams", type=int, default=2, choices=[1, 2, 3, 4],
@@ -470,7 +470,8 @@ def main():
     out = torch.empty_like(vox)
     # pipeline >= 2: several bricksets in flight (see run_steps); the serial per-kernel pass below reuses the
     # first of them, so no further set (65 GB at the full volume) is allocated after the pipelined ones
-    NS = args.pipeline                 # bricksets in flight
+    # bricksets in flight (more than 3 measured slower at every brick count: 120, 240, 960)
+    NS = args.pipeline or 3
     sets = []
     torch.cuda.synchronize()
     free_before_sets = torch.cuda.mem_get_info()[0]      # the library allocates with hipMalloc, outside torch's caching allocator
