@@ -772,3 +772,30 @@ def test_level_loop_concurrency_does_not_change_results(vr, oracle):
         assert got[2][0][i] == ref.tree.tobytes() and list(got[2][1][i]) == list(ref.distanceMap)
     with pytest.raises(vr.VrError):
         vr.BrickSet(1, (x, y, z), 1, 2).set_concurrency(5)
+
+
+def test_leafless_builds_across_epoch_settings_on_one_handle(vr, oracle):
+    """A fused build stores nothing of the leaf level and recomputes it in the prune from the distances the level loop
+    ended with (Ctrl::finalReconDist / finalCodesDist, which differ after reverted epochs); an epoch one step beside
+    the previous fill reads that fill's central-difference partials instead of running a fill.  One handle through
+    setMaxEpochs 5 -> 0 -> 2 -> 1 (0 switches the handle to the storing mode and back: the encoder's arrays are made
+    again) and tolerances 0 / 1 / 3, volumes with and without reverts: every build equals the oracle's."""
+    rng = np.random.default_rng(77)
+    vols = [rng.integers(0, 256, (32, 32, 32), dtype=np.uint8), oracle.gen_sphere(32, 7), rm_like((16, 32, 64), 5),
+            (rng.integers(0, 4, (32, 32, 32)) + 1).astype(np.uint8)]           # the last one: small values, clamps at 0 matter
+    reverts = 0
+    for vol in vols:
+        z, y, x = vol.shape
+        bs = vr.BrickSet(1, (x, y, z), 1, 5)
+        for ep, tol in ((5, 0), (0, 1), (2, 1), (1, 3), (5, 1), (0, 0), (3, 0)):
+            bs.set_max_epochs(ep)
+            bs.set_error_tolerance(tol)
+            bs.build(vol.copy())
+            ref = oracle.OracleTree(vol.copy(), tolerance=tol, max_epochs=ep).build()
+            reverts += ref.numReverts
+            info = bs.info(0)
+            assert info["num_active_nodes"] == ref.numActiveNodes and info["num_reverts"] == ref.numReverts, (ep, tol)
+            assert list(bs.distance_map(0)) == list(ref.distanceMap), (ep, tol)
+            assert np.array_equal(bs.tree(0), ref.tree), (ep, tol)
+            assert np.array_equal(bs.decode().cpu().numpy().reshape(z, y, x), ref.levelCut()), (ep, tol)
+    assert reverts >= 1
