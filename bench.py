@@ -391,7 +391,7 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="skip the MidRangeTree / config-5 streaming leg")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3, 4, 6, 8],
                     help="bricksets in flight, each on its own stream with its own output volume.  0 (default) = 3 (~59 GB "
-                         "each of the 288 GB for a whole volume): build + levelCut of steps k, k+1, k+2 run beside each other (the streaming "
+                         "each of the 288 GB for a whole volume; 4 where a rank holds a fraction of the volume): build + levelCut of steps k, k+1, k+2 run beside each other (the streaming "
                          "use: the next timesteps compress while this one decodes; falls back to 2 if the third set "
                          "does not fit); 1: strictly serial")
     ap.add_argument("--level-loop-streams", type=int, default=2, choices=[1, 2, 3, 4],
@@ -470,8 +470,10 @@ def main():
     out = torch.empty_like(vox)
     # pipeline >= 2: several bricksets in flight (see run_steps); the serial per-kernel pass below reuses the
     # first of them, so no further set (65 GB at the full volume) is allocated after the pipelined ones
-    # bricksets in flight (more than 3 measured slower at every brick count: 120, 240, 960)
-    NS = args.pipeline or 3
+    # bricksets in flight: 3 for a whole volume per GPU (a fourth does not fit beside them usefully: 36.5 instead of 35.9 ms);
+    # 4 for a rank that holds a fraction of the volume (strong scaling), where a build's latency-bound control steps
+    # weigh more (one rank's y-slab at N = 2 / 8: 17.6 -> 17.0 / 5.3 -> 5.0 ms per step; 5 or 6 sets: slower again)
+    NS = args.pipeline or (3 if B >= 960 else 4)
     sets = []
     torch.cuda.synchronize()
     free_before_sets = torch.cuda.mem_get_info()[0]      # the library allocates with hipMalloc, outside torch's caching allocator
