@@ -474,6 +474,9 @@ def main():
     # 4 for a rank that holds a fraction of the volume (strong scaling), where a build's latency-bound control steps
     # weigh more (one rank's y-slab at N = 2 / 8: 17.6 -> 17.0 / 5.3 -> 5.0 ms per step; 5 or 6 sets: slower again)
     NS = args.pipeline or (3 if B >= 960 else 4)
+    # level-loop forks inside a pipelined set: none for a whole or half volume (the other sets fill the gaps), two brick
+    # ranges for a quarter or less (one rank's y-slab at N = 4 / 8: 10.6 -> 9.9 / 6.2 -> 5.8 ms per step; N = 2: slower)
+    lls_pipe = 2 if B <= 240 else 1
     sets = []
     torch.cuda.synchronize()
     free_before_sets = torch.cuda.mem_get_info()[0]      # the library allocates with hipMalloc, outside torch's caching allocator
@@ -481,7 +484,7 @@ def main():
         try:
             sets = [vr.BrickSet(B, bdims, args.tolerance, args.max_epochs) for _ in range(NS)]
             for s_ in sets:            # several sets in flight fill each other's gaps: no fork inside a build (vrhip.h)
-                s_.set_concurrency(1 if NS >= 2 else args.level_loop_streams)
+                s_.set_concurrency(lls_pipe if NS >= 2 else args.level_loop_streams)
             for s_ in sets:            # setup, not a step: allocate and first-touch every set's buffers
                 s_.build(vox); s_.decode(out)
             torch.cuda.synchronize()
@@ -632,7 +635,7 @@ def main():
                                   + "%s, tolerance %d, maxEpochs %d, VolumeKdtree build + levelCut" % (args.kind, args.tolerance, args.max_epochs),
                       "pipeline": ("%d bricksets in flight, each on its own stream: build + levelCut of step k run "
                                    "beside those of the following steps" % NS if NS >= 2 else "serial"),
-                      "level_loop_streams": {"pipelined": 1 if NS >= 2 else args.level_loop_streams, "serial": args.level_loop_streams},
+                      "level_loop_streams": {"pipelined": lls_pipe if NS >= 2 else args.level_loop_streams, "serial": args.level_loop_streams},
                       "constant_bricks": int(n_const),
                       "tokens_per_voxel": round(tokens / float(V * B), 3),
                       "compression_ratio": round(float(V * B) / (tokens / 4.0), 2)},
