@@ -383,13 +383,27 @@ __device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int
 }
 
 // exact in-order walk of nodes [lo, hi) by one wave; (S,C) are wave-uniform
+#define EST_STAGE_NODES 4096        // est_exact_chain's LDS staging area holds this many truths and half as many parents
 __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, uint32_t lo,
-                                       uint32_t hi, unsigned long long &S, uint32_t &C, int lane, const SkipBlocks &sk, int brick)
+                                       uint32_t hi, unsigned long long &S, uint32_t &C, int lane, const SkipBlocks &sk, int brick,
+                                       uint8_t *stage = nullptr)
 {
+    // A walk is a chain of 64-node steps, each waiting for its bytes: with the next step's loads in flight it still ran at
+    // one memory round trip per step (50 us for the 4096 nodes k_est_head walks on every level).  Ranges that fit are
+    // staged in LDS by ONE batch of 16-byte loads (this wave is the workgroup: its LDS accesses are ordered).
+    const uint32_t len = hi - lo;
+    const bool staged = stage && d > 0 && len >= 64u && len <= (uint32_t)EST_STAGE_NODES && (len & 63u) == 0u && (lo & 31u) == 0u;
+    const uint8_t *sT = stage, *sP = stage + EST_STAGE_NODES;
+    if (staged) {
+        for (uint32_t i = (uint32_t)lane * 16u; i < len; i += 1024u) *(uint4 *)(stage + i) = *(const uint4 *)(T + lo + i);
+        for (uint32_t i = (uint32_t)lane * 16u; i < len / 2u; i += 1024u) *(uint4 *)(stage + EST_STAGE_NODES + i) = *(const uint4 *)(P + (lo >> 1) + i);
+    }
     // the next 64 nodes are in flight while these are decided (the walk is latency-bound otherwise); chunks inside a
     // skipped block (SkipBlocks: nothing there counts, and its parents' reconstruction is not in memory) are passed over
     const bool sk0 = skip_block(sk, brick, d, lo);
-    int tn = (!sk0 && lo + lane < hi) ? T[lo + lane] : 0, pn = (!sk0 && lo + lane < hi && d > 0) ? P[(lo + lane) >> 1] : 0;
+    int tn = 0, pn = 0;
+    if (staged) { tn = sT[lane]; pn = sP[lane >> 1]; }
+    else { tn = (!sk0 && lo + lane < hi) ? T[lo + lane] : 0; pn = (!sk0 && lo + lane < hi && d > 0) ? P[(lo + lane) >> 1] : 0; }
     bool skipThis = sk0;
     for (uint32_t base = lo; base < hi; base += 64) {
         uint32_t i = base + lane;
@@ -399,8 +413,14 @@ __device__ inline void est_exact_chain(const uint8_t *__restrict__ T, const uint
         {
             const uint32_t i2 = i + 64;
             skipThis = base + 64 < hi && skip_block(sk, brick, d, base + 64);
-            tn = (!skipThis && i2 < hi) ? T[i2] : 0;
-            pn = (!skipThis && i2 < hi && d > 0) ? P[i2 >> 1] : 0;
+            if (staged) {
+                const uint32_t j2 = i2 - lo;
+                tn = j2 < len ? sT[j2] : 0;
+                pn = j2 < len ? sP[j2 >> 1] : 0;
+            } else {
+                tn = (!skipThis && i2 < hi) ? T[i2] : 0;
+                pn = (!skipThis && i2 < hi && d > 0) ? P[i2 >> 1] : 0;
+            }
         }
         if (skipped) continue;
         int pd = p > t ? p - t : t - p;
@@ -459,7 +479,8 @@ k_est_head(int d, int maxEpochs, Ctrl *ctrls, const uint8_t *__restrict__ temp, 
     const uint32_t n = 1u << d;
     unsigned long long S = 0;
     uint32_t C = 0;
-    est_exact_chain(T, P, d, 0, n < EST_HEAD ? n : EST_HEAD, S, C, lane, sk, brick);
+    __shared__ __attribute__((aligned(16))) uint8_t stage[EST_STAGE_NODES + EST_STAGE_NODES / 2];
+    est_exact_chain(T, P, d, 0, n < EST_HEAD ? n : EST_HEAD, S, C, lane, sk, brick, stage);
     if (lane == 0) {
         if (n <= EST_HEAD) est_finish(c, S, C, maxEpochs);
         else {
@@ -597,6 +618,7 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
     const uint32_t n = 1u << d, nseg = n / EST_SEG;
     const uint32_t *sm = summ + (int64_t)brick * summStride * (4 * EST_CAND);
     if (c.constBrick || c.estDone) return;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[EST_STAGE_NODES + EST_STAGE_NODES / 2];    // est_exact_chain's (a failed segment)
     unsigned long long S = c.estS;
     uint32_t C = c.estC;
     const int Tbase = c.estTbase;
@@ -654,7 +676,7 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
         S += lane_u32(si - ss, f);
         C += lane_u32(sci - sc, f);
         seg += f;
-        est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane, sk, brick);
+        est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane, sk, brick, stage);
         Tc = (long long)(S / (2ull * C + 1ull));
         seg += 1;
         ++fallbacks;
