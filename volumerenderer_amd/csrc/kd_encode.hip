@@ -625,10 +625,22 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
     long long Tc = (long long)(S / (2ull * C + 1ull));
     uint32_t seg = (uint32_t)c.estSeg;
     int fallbacks = 0;
-    // the next 64 records are fetched while the current ones are checked (same candidate: the common case)
-    uint32_t preSeg = 0xFFFFFFFFu, preS = 0, preC = 0;
+    // 256 segments per step, four consecutive ones per lane (64 contiguous bytes of its candidate's plane), the next
+    // step's records in flight while these are checked (same candidate: the common case).  (64 per step, one per lane:
+    // 128 steps of one memory round trip each on the leaf level, 220 us.)
+    uint32_t preSeg = 0xFFFFFFFFu;
     long long preCi = -1;
-    int preA = 0, preB = 0;
+    uint4 pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = make_uint4(0, 0, 0x80000000u, 0x7FFFFFFFu);
+    const auto fetch = [&](long long ci_, uint32_t seg_, uint4 (&r)[4]) {
+        const uint32_t k0 = seg_ + 4u * (uint32_t)lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = make_uint4(0, 0, 0x80000000u, 0x7FFFFFFFu);          // (sums 0, A = INT_MIN, B = INT_MAX: always true)
+            if (k0 + (uint32_t)j < nseg) r[j] = *(const uint4 *)(sm + est_at((int)ci_, k0 + (uint32_t)j));
+        }
+    };
     while (seg < nseg) {
         const long long ci = Tc - Tbase;
         if (ci < 0 || ci >= nc) {            // threshold left the candidate window
@@ -644,38 +656,38 @@ k_est_walk(int d, int maxEpochs, int nc, int ncNext, int lastRound, Ctrl *ctrls,
             fallbacks += (int)(nseg - seg);
             break;
         }
-        const uint32_t k = seg + lane;
-        const bool valid = k < nseg;
-        uint32_t ss = 0, sc = 0;
-        int A = INT32_MIN, B = INT32_MAX;
-        if (preSeg == seg && preCi == ci) { ss = preS; sc = preC; A = preA; B = preB; }
-        else if (valid) {
-            const uint4 r = *(const uint4 *)(sm + est_at((int)ci, k));
-            ss = r.x; sc = r.y; A = (int)r.z; B = (int)r.w;
+        uint4 r[4];
+        if (preSeg == seg && preCi == ci) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = pre[j];
+        } else fetch(ci, seg, r);
+        preSeg = seg + 256u; preCi = ci;
+        fetch(ci, preSeg, pre);
+        const uint32_t k0 = seg + 4u * (uint32_t)lane;
+        const uint32_t ssL = r[0].x + r[1].x + r[2].x + r[3].x, scL = r[0].y + r[1].y + r[2].y + r[3].y;
+        const uint32_t si = wave_incl_scan_u32(ssL, lane), sci = wave_incl_scan_u32(scL, lane);
+        uint32_t eS = si - ssL, eC = sci - scL;              // sums of the segments before mine in this step
+        int failJ = 4;
+        uint32_t fS = 0, fC = 0;                             // ... and before my first failing segment
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long S0 = (long long)S + (long long)eS;
+            const long long q = 2ll * ((long long)C + (long long)eC) + 1ll;
+            const bool ok = k0 + (uint32_t)j >= nseg || (S0 - Tc * q >= (long long)(int)r[j].z && S0 - (Tc + 1) * q < (long long)(int)r[j].w);
+            if (!ok && failJ == 4) { failJ = j; fS = eS; fC = eC; }
+            eS += r[j].x; eC += r[j].y;
         }
-        {
-            const uint32_t k2 = k + 64;
-            preSeg = seg + 64; preCi = ci; preS = 0; preC = 0; preA = INT32_MIN; preB = INT32_MAX;
-            if (k2 < nseg) {
-                const uint4 r = *(const uint4 *)(sm + est_at((int)ci, k2));
-                preS = r.x; preC = r.y; preA = (int)r.z; preB = (int)r.w;
-            }
-        }
-        const uint32_t si = wave_incl_scan_u32(ss, lane), sci = wave_incl_scan_u32(sc, lane);
-        const long long S0 = (long long)S + (long long)(si - ss);
-        const long long q = 2ll * ((long long)C + (long long)(sci - sc)) + 1ll;
-        const bool ok = !valid || (S0 - Tc * q >= (long long)A && S0 - (Tc + 1) * q < (long long)B);
-        const unsigned long long bad = ~__ballot(ok);
+        const unsigned long long bad = __ballot(failJ < 4);
         if (bad == 0ull) {
             S += lane_u32(si, 63);
             C += lane_u32(sci, 63);
-            seg += 64;
+            seg += 256u;
             continue;
         }
-        const int f = __ffsll((long long)bad) - 1;            // first segment whose hypothesis fails
-        S += lane_u32(si - ss, f);
-        C += lane_u32(sci - sc, f);
-        seg += f;
+        const int f = __ffsll((long long)bad) - 1;            // the lane of the first segment whose hypothesis fails
+        S += lane_u32(fS, f);
+        C += lane_u32(fC, f);
+        seg += 4u * (uint32_t)f + lane_u32((uint32_t)failJ, f);
         est_exact_chain(T, P, d, seg * EST_SEG, (seg + 1) * EST_SEG, S, C, lane, sk, brick, stage);
         Tc = (long long)(S / (2ull * C + 1ull));
         seg += 1;
