@@ -394,9 +394,11 @@ def main():
                          "each of the 288 GB for a whole volume; 4 where a rank holds a fraction of the volume): build + levelCut of steps k, k+1, k+2 run beside each other (the streaming "
                          "use: the next timesteps compress while this one decodes; falls back to 2 if the third set "
                          "does not fit); 1: strictly serial")
-    ap.add_argument("--level-loop-streams", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="vr_brickset_set_concurrency for the strictly serial pass (library default 2; 1 for clean "
-                         "per-kernel profiles).  The pipelined sets always use 1")
+    ap.add_argument("--level-loop-streams", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="vr_brickset_set_concurrency for the strictly serial pass: brick ranges whose level loops run side "
+                         "by side on internal streams (4 = the most the library takes and the fastest single build; the "
+                         "library's own default is 2, which leaves a hardware queue to a caller's copy stream; 1 for clean "
+                         "per-kernel profiles).  The pipelined sets use 1 (2 for a quarter volume or less)")
     ap.add_argument("--no-extra-timing", action="store_true", help="skip the second timed pass (value_no_compact)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong (default, BASELINE config 4) = ONE volume, its bricks dealt to the ranks by slabs of the "
@@ -573,7 +575,7 @@ def main():
 
     # per-kernel timing outside the timed region, strictly serial: hipEvents on the launch stream
     # (vr_brickset_last_timings)
-    bs.set_concurrency(args.level_loop_streams)      # default 2 = the library's: what a single build() call gets
+    bs.set_concurrency(args.level_loop_streams)      # default 4: the fastest single build() (vr_brickset_set_concurrency)
     enc_ms, dec_ms = [], []
     for i in range(4):
         bs.build(vox)
