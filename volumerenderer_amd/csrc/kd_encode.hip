@@ -1010,11 +1010,12 @@ __device__ inline double ctl_walk_block16(double s, const uint8_t *__restrict__ 
 
 // 64 partials (1024 nodes each) starting at block `base`, added in order: whole partials while the sum stays inside
 // its binade, the crossing block node by node
-__device__ inline double ctl_partials64(double s, const unsigned long long *__restrict__ be, uint32_t base, uint32_t nblk,
+#define CTL_STAGE_BLOCKS 8192       // k_control keeps a level's per-block partials in LDS when there are at most this many (32 KiB)
+__device__ inline double ctl_partials64(double s, const unsigned long long *__restrict__ be, const uint32_t *stg, uint32_t base, uint32_t nblk,
                                         const uint8_t *__restrict__ T, const uint8_t *__restrict__ P, int d, int dist,
                                         uint32_t n, int lane)
 {
-    const unsigned long long e2 = base + lane < nblk ? be[base + lane] : 0ull;
+    const unsigned long long e2 = base + lane < nblk ? (stg ? (unsigned long long)stg[base + lane] : be[base + lane]) : 0ull;
     // two 32-bit DPP scans (24-bit limbs: 64 partials of < 2^27 each cannot overflow either)
     const unsigned long long incl = (unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 & 0xFFFFFFull)) +
                                     ((unsigned long long)wave_incl_scan_add_dpp((uint32_t)(e2 >> 24)) << 24);
@@ -1046,6 +1047,7 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
           int leaflessLeaf)
 {
     const int brick = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t ctlStage[CTL_STAGE_BLOCKS];
     Ctrl &c = ctrls[brick];
     if (c.constBrick) return;
     const uint32_t n = 1u << d;
@@ -1062,10 +1064,25 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
         // which it crosses a power of two is opened (ctl_partials64, which opens only the crossing block).  A level
         // has ~log2 crossings, so this touches a handful of chunks instead of stepping through all of them.
         const uint32_t nchunk = (nblk + 63u) >> 6;
+        // the partials (each < 2^27) go to LDS in one batch of coalesced loads: the chunk sums and every chunk that is
+        // opened below then cost no memory round trip (64 uncoalesced 8-byte loads per lane in dependent batches, and
+        // one more round trip per opened chunk, were a third of this kernel's 25-75 us)
+        const uint32_t *stg = nullptr;
+        if (nblk >= 256u && nblk <= (uint32_t)CTL_STAGE_BLOCKS && (nblk & 255u) == 0u) {
+            for (uint32_t i = (uint32_t)lane * 4u; i < nblk; i += 256u) {
+                const uint4 a = *(const uint4 *)(be + i), b = *(const uint4 *)(be + i + 2);
+                *(uint4 *)(ctlStage + i) = make_uint4(a.x, a.z, b.x, b.z);
+            }
+            stg = ctlStage;
+        }
         for (uint32_t cb = 0; cb < nchunk; cb += 64) {
             const uint32_t ch = cb + (uint32_t)lane;
             unsigned long long tot = 0;
-            if (ch < nchunk) {
+            if (ch < nchunk && stg) {
+                const uint32_t *q = stg + (size_t)ch * 64;      // (whole chunks: nblk is a multiple of 256)
+#pragma unroll 8
+                for (int k = 0; k < 64; ++k) tot += q[(k + lane) & 63];      // rotated: the lanes' rows sit 64 words apart
+            } else if (ch < nchunk) {
                 const unsigned long long *q = be + (size_t)ch * 64;
                 const uint32_t m = nblk - ch * 64 < 64u ? nblk - ch * 64 : 64u;
                 if (m == 64u) {
@@ -1089,7 +1106,7 @@ k_control(int d, int maxEpochs, int guarded, Ctrl *ctrls, const uint8_t *__restr
                 const int f = __ffsll((long long)bad) - 1;
                 const unsigned long long exclF = lane_u64(incl - tot, f), inclF = lane_u64(incl, f);
                 s = s + (double)(exclF - consumed);       // exact: still inside the binade
-                s = ctl_partials64(s, be, (cb + (uint32_t)f) * 64u, nblk, T, P, d, dist, n, lane);
+                s = ctl_partials64(s, be, stg, (cb + (uint32_t)f) * 64u, nblk, T, P, d, dist, n, lane);
                 consumed = inclF;
                 start = f + 1;
             }
