@@ -399,6 +399,8 @@ def main():
                          "by side on internal streams (4 = the most the library takes and the fastest single build; the "
                          "library's own default is 2, which leaves a hardware queue to a caller's copy stream; 1 for clean "
                          "per-kernel profiles).  The pipelined sets use 1 (2 for a quarter volume or less)")
+    ap.add_argument("--pipeline-level-loop-streams", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="vr_brickset_set_concurrency of the pipelined sets (0 = 1 for half a volume or more, 2 below)")
     ap.add_argument("--no-extra-timing", action="store_true", help="skip the second timed pass (value_no_compact)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong (default, BASELINE config 4) = ONE volume, its bricks dealt to the ranks by slabs of the "
@@ -478,7 +480,7 @@ def main():
     NS = args.pipeline or (3 if B >= 960 else 4)
     # level-loop forks inside a pipelined set: none for a whole or half volume (the other sets fill the gaps), two brick
     # ranges for a quarter or less (one rank's y-slab at N = 4 / 8: 10.6 -> 9.9 / 6.2 -> 5.8 ms per step; N = 2: slower)
-    lls_pipe = 2 if B <= 240 else 1
+    lls_pipe = args.pipeline_level_loop_streams or (2 if B <= 240 else 1)
     sets = []
     torch.cuda.synchronize()
     free_before_sets = torch.cuda.mem_get_info()[0]      # the library allocates with hipMalloc, outside torch's caching allocator
