@@ -168,6 +168,17 @@ __device__ __forceinline__ int wave_max_i32_dpp(int v)   // result valid in lane
     v = max(v, (int)dpp_u32<0x143, 0xc>(I, (uint32_t)v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_min_i32_dpp(int v)   // result valid in lane 63 (returned via readlane)
+{
+    const uint32_t I = 0x7FFFFFFFu;
+    v = min(v, (int)dpp_u32<0x111, 0xf>(I, (uint32_t)v));
+    v = min(v, (int)dpp_u32<0x112, 0xf>(I, (uint32_t)v));
+    v = min(v, (int)dpp_u32<0x114, 0xf>(I, (uint32_t)v));
+    v = min(v, (int)dpp_u32<0x118, 0xf>(I, (uint32_t)v));
+    v = min(v, (int)dpp_u32<0x142, 0xa>(I, (uint32_t)v));
+    v = min(v, (int)dpp_u32<0x143, 0xc>(I, (uint32_t)v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 #endif
 

@@ -599,7 +599,7 @@ k_est_summ(int d, int nc, Ctrl *ctrls, const uint8_t *__restrict__ temp, int64_t
         a += 2 * Th * c0 - s0;
         b += 2 * (Th + 1) * c0 - s0;
         a = wave_max_i32_dpp(a);
-        b = -wave_max_i32_dpp(-b);
+        b = wave_min_i32_dpp(b);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (lane < 4)
             out[est_at(ci, seg) + lane] = lane == 0 ? (tot & 0xFFFFFu) : (lane == 1 ? (tot >> 20) : (lane == 2 ? (uint32_t)a : (uint32_t)b));
